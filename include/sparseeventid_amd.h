@@ -1,0 +1,138 @@
+/*
+ * sparseeventid_amd.h -- C ABI of the MI355X (gfx950) submanifold sparse-convolution engine.
+ *
+ * This is the drop-in boundary for the ONE hot path of coreyjadams/SparseEventID:
+ * the `sparseconvnet` (scn) operators composed by the reference network
+ *   /root/reference/src/networks/resnet.py:26-50,105-110,124-125,141-161
+ *   /root/reference/src/networks/sparse_building_blocks.py:29-34,39,80,96,110-117,122
+ * The reference binds these through the third-party python package `sparseconvnet`
+ * (its pybind11 extension `sparseconvnet.SCN`, absent from the reference tree); each
+ * entry point below names the scn operator / SCN function family it replaces.
+ *
+ * Conventions
+ *  - plain C: pointers + sizes, no torch types.  All `*_dev` / feature pointers are
+ *    DEVICE pointers owned by the caller (PyTorch); the library only borrows them for
+ *    the duration of the call.  Metadata / rulebooks are owned by the library.
+ *  - every function returns 0 on success, non-zero on error; sei_last_error() returns a
+ *    thread-local message (the python binding raises RuntimeError with it).
+ *  - `stream` is a hipStream_t passed as void*; all work is enqueued on it; no hidden
+ *    hipDeviceSynchronize.  Functions that must return a count to the host synchronise
+ *    that stream only (documented per function).
+ *  - handles carry no thread-local state: safe to use from the autograd thread.
+ *  - coordinates: int32 [N,4] = (x0, x1, x2, batch), the layout the reference transform
+ *    emits (src/io/data_transforms.py:36-46).
+ *  - features: fp32 row-major [N, C].  weights: fp32 [K, nIn, nOut], k row-major over the
+ *    filter (last dim fastest) -- the scn parameter layout (state_dict contract).
+ */
+#ifndef SPARSEEVENTID_AMD_H
+#define SPARSEEVENTID_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sei_metadata sei_metadata_t; /* scn.Metadata: hash maps + rulebooks, all levels */
+typedef struct sei_rulebook sei_rulebook_t; /* one (level, filter, stride) rulebook; owned by metadata */
+typedef void *sei_stream_t;                 /* hipStream_t */
+
+const char *sei_last_error(void);
+int sei_abi_version(void);
+
+/* ---- metadata (replaces scn.Metadata / SCN `Metadata<3>`) ------------------------------- */
+int sei_metadata_create(sei_metadata_t **out);
+void sei_metadata_destroy(sei_metadata_t *m);
+
+/* scn.InputLayer(dimension=3, spatial_size, mode) coordinate pass (resnet.py:40-43,143;
+ * SCN `setInputSpatialLocations` / `inputLayerRules`).  Builds the level-0 hash map on the
+ * device from coords_dev[n,4]; duplicates collapse to one row (first-appearance order).
+ * mode: 0/2 keep first, 1 keep last, 3 sum, 4 mean.  Out-of-range coordinates are an error.
+ * Synchronises `stream` to return *n_rows. */
+int sei_input_build(sei_metadata_t *m, const int32_t *coords_dev, int64_t n, const int32_t spatial[3],
+                    int32_t batch_size, int32_t mode, sei_stream_t stream, int64_t *n_rows);
+/* InputLayer feature pass: out[n_rows,C] from in[n,C] (SCN `InputLayer_updateOutput`). */
+int sei_input_features_fwd(sei_metadata_t *m, const float *in, int32_t C, float *out, sei_stream_t stream);
+/* ... and its gradient (SCN `InputLayer_updateGradInput`): din[n,C] from dout[n_rows,C]. */
+int sei_input_features_bwd(sei_metadata_t *m, const float *dout, int32_t C, float *din, sei_stream_t stream);
+
+/* level queries (scn.SparseConvNetTensor.get_spatial_locations) */
+int sei_level_rows(sei_metadata_t *m, const int32_t spatial[3], int64_t *n_rows);
+int sei_level_coords(sei_metadata_t *m, const int32_t spatial[3], int32_t *coords_out_dev, sei_stream_t stream);
+int sei_batch_size(sei_metadata_t *m, int32_t *batch_size);
+
+/* ---- rulebooks (SCN `getSubmanifoldRuleBook` / `getRuleBook`) ---------------------------- */
+/* Cached in the metadata per (spatial, filter).  Synchronises `stream` on first build. */
+int sei_subm_rulebook(sei_metadata_t *m, const int32_t spatial[3], const int32_t filter[3],
+                      sei_stream_t stream, sei_rulebook_t **rb);
+/* scn.Convolution: discovers the output active set (new level, spatial_out), builds the
+ * forward rulebook and its transpose.  Synchronises `stream` on first build. */
+int sei_conv_rulebook(sei_metadata_t *m, const int32_t spatial_in[3], const int32_t size[3],
+                      const int32_t stride[3], sei_stream_t stream, sei_rulebook_t **rb,
+                      int32_t spatial_out[3]);
+/* info[0]=n_dst rows, [1]=n_src rows, [2]=K, [3]=rules, [4]=chunks (32 slots each), [5]=tiles */
+int sei_rulebook_info(const sei_rulebook_t *rb, int64_t info[6]);
+/* copy the rules out as k-major (in,out) lists for inspection/tests: start[K+1] (host),
+ * rules_in/out device int32 [rules].  Synchronises. */
+int sei_rulebook_export(sei_rulebook_t *rb, int64_t *start_host, int32_t *rules_in_dev,
+                        int32_t *rules_out_dev, sei_stream_t stream);
+
+/* ---- convolution arithmetic (scn.SubmanifoldConvolution / scn.Convolution;
+ *      SCN `SubmanifoldConvolution_updateOutput` / `_backward`, `Convolution_*`) ------------ */
+/* Y[n_dst,nOut] = bias + sum_k X[rule.in] * W[k]   (bias may be NULL) */
+int sei_conv_forward(sei_rulebook_t *rb, const float *X, const float *W, const float *bias, float *Y,
+                     int32_t nIn, int32_t nOut, sei_stream_t stream);
+/* dX[n_src,nIn] = sum_k dY[rule.out] * W[k]^T */
+int sei_conv_backward_input(sei_rulebook_t *rb, const float *dY, const float *W, float *dX,
+                            int32_t nIn, int32_t nOut, sei_stream_t stream);
+/* dW[K,nIn,nOut] = sum_rules X[rule.in]^T dY[rule.out]; dbias[nOut] = colsum(dY) if non-NULL */
+int sei_conv_backward_weight(sei_rulebook_t *rb, const float *X, const float *dY, float *dW, float *dbias,
+                             int32_t nIn, int32_t nOut, sei_stream_t stream);
+
+/* ---- BatchNormalization (+fused LeakyReLU, +fused residual AddTable)
+ *      (scn.BatchNormalization / BatchNormLeakyReLU / BatchNormReLU + scn.AddTable + scn.LeakyReLU;
+ *       sparse_building_blocks.py:39,80,96,122; SCN `BatchNormalization_updateOutput/_backward`) */
+/* training: batch stats over all n rows (biased var, eps inside rsqrt), running stats updated
+ *   r = momentum*r + (1-momentum)*batch (running var unbiased).  eval: uses running stats.
+ * y = leaky(gamma*(x-mean)*invstd + beta [+ residual], leak);  leak==1 -> identity.
+ * save_mean/save_invstd [C] receive the statistics used. gamma/beta may be NULL (affine off). */
+int sei_bn_forward(const float *x, int64_t n, int32_t C, const float *gamma, const float *beta,
+                   float *running_mean, float *running_var, float eps, float momentum, int32_t training,
+                   float leak, const float *residual, float *y, float *save_mean, float *save_invstd,
+                   sei_stream_t stream);
+/* backward of the above (training statistics): needs x, y (for the activation sign), dy.
+ * dx [n,C]; dresidual [n,C] or NULL; dgamma/dbeta [C] or NULL. */
+int sei_bn_backward(const float *x, const float *y, const float *dy, int64_t n, int32_t C,
+                    const float *gamma, const float *save_mean, const float *save_invstd, float leak,
+                    int32_t training, float *dx, float *dresidual, float *dgamma, float *dbeta,
+                    sei_stream_t stream);
+
+/* ---- elementwise (scn.LeakyReLU / scn.ReLU / scn.AddTable) -------------------------------- */
+int sei_leaky_forward(const float *x, float *y, int64_t count, float leak, sei_stream_t stream);
+int sei_leaky_backward(const float *y, const float *dy, float *dx, int64_t count, float leak, sei_stream_t stream);
+int sei_add_forward(const float *a, const float *b, float *out, int64_t count, sei_stream_t stream);
+/* y = leaky(a + b) fused AddTable + LeakyReLU (sparse_building_blocks.py:96-98) */
+int sei_add_leaky_forward(const float *a, const float *b, float *y, int64_t count, float leak, sei_stream_t stream);
+
+/* ---- scn.SparseToDense (resnet.py:124-125,156; SCN `SparseToDense_updateOutput`) ---------- */
+/* dense [B,C,D0,D1,D2] (zero-filled by this call), rows scattered by coordinate. */
+int sei_sparse_to_dense_forward(sei_metadata_t *m, const int32_t spatial[3], const float *feats, int32_t C,
+                                float *dense, sei_stream_t stream);
+int sei_sparse_to_dense_backward(sei_metadata_t *m, const int32_t spatial[3], const float *ddense, int32_t C,
+                                 float *dfeats, sei_stream_t stream);
+
+/* ---- measurement hooks (bench.py roofline leg): HIP events around each conv launch -------- */
+/* kinds: 0 conv_fwd, 1 conv_bwd_input, 2 conv_bwd_weight, 3 rulebook_build, 4 batchnorm, 5 other */
+int sei_prof_enable(int32_t on);
+int sei_prof_reset(void);
+/* Synchronises outstanding events.  out = {launches, total_ms, algorithmic flops, algorithmic bytes} */
+int sei_prof_query(int32_t kind, double out[4]);
+
+/* library-owned device memory (rulebooks, scratch): bytes currently held by the pool */
+int sei_pool_stats(int64_t *bytes_held, int64_t *bytes_in_use);
+int sei_pool_trim(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,410 @@
+// C ABI glue (include/sparseeventid_amd.h): error state, device pool, profiling, handle management.
+#include "common.h"
+
+#include <string.h>
+
+namespace sei {
+
+// ---------------------------------------------------------------- errors
+static thread_local std::string g_error;
+void set_error(const std::string &msg) { g_error = msg; }
+
+// ---------------------------------------------------------------- pool
+namespace {
+struct Pool {
+    std::mutex mu;
+    std::multimap<size_t, void *> free_blocks;
+    std::map<void *, size_t> live;
+    size_t held = 0, in_use = 0;
+} g_pool;
+
+size_t round_size(size_t b) {
+    if (b < 256) return 256;
+    if (b <= (1u << 20)) {  // powers of two below 1 MiB
+        size_t s = 256;
+        while (s < b) s <<= 1;
+        return s;
+    }
+    const size_t g = 1u << 20;  // 1 MiB granules above
+    return (b + g - 1) / g * g;
+}
+}  // namespace
+
+void *pool_alloc(size_t bytes) {
+    size_t sz = round_size(bytes);
+    std::lock_guard<std::mutex> lk(g_pool.mu);
+    auto it = g_pool.free_blocks.lower_bound(sz);
+    if (it != g_pool.free_blocks.end() && it->first <= sz + sz / 4 + (1u << 20)) {
+        void *p = it->second;
+        size_t got = it->first;
+        g_pool.free_blocks.erase(it);
+        g_pool.live[p] = got;
+        g_pool.in_use += got;
+        return p;
+    }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, sz);
+    if (e != hipSuccess) {
+        // release cached blocks and retry once
+        for (auto &kv : g_pool.free_blocks) {
+            (void)hipFree(kv.second);
+            g_pool.held -= kv.first;
+        }
+        g_pool.free_blocks.clear();
+        (void)hipGetLastError();
+        e = hipMalloc(&p, sz);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+    }
+    g_pool.held += sz;
+    g_pool.in_use += sz;
+    g_pool.live[p] = sz;
+    return p;
+}
+
+void pool_free(void *p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(g_pool.mu);
+    auto it = g_pool.live.find(p);
+    if (it == g_pool.live.end()) return;
+    g_pool.free_blocks.emplace(it->second, p);
+    g_pool.in_use -= it->second;
+    g_pool.live.erase(it);
+}
+
+// ---------------------------------------------------------------- profiling
+namespace {
+struct ProfRec {
+    hipEvent_t e0, e1;
+    double flops, bytes;
+};
+struct Prof {
+    std::mutex mu;
+    bool on = false;
+    std::vector<ProfRec> recs[PROF_NKIND];
+    std::vector<hipEvent_t> spare;
+    double ms[PROF_NKIND] = {0}, flops[PROF_NKIND] = {0}, bytes[PROF_NKIND] = {0};
+    double launches[PROF_NKIND] = {0};
+} g_prof;
+
+hipEvent_t get_event() {
+    if (!g_prof.spare.empty()) {
+        hipEvent_t e = g_prof.spare.back();
+        g_prof.spare.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+void drain_locked() {
+    for (int k = 0; k < PROF_NKIND; k++) {
+        for (auto &r : g_prof.recs[k]) {
+            float ms = 0.f;
+            if (hipEventSynchronize(r.e1) == hipSuccess && hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+                g_prof.ms[k] += ms;
+                g_prof.flops[k] += r.flops;
+                g_prof.bytes[k] += r.bytes;
+                g_prof.launches[k] += 1;
+            }
+            g_prof.spare.push_back(r.e0);
+            g_prof.spare.push_back(r.e1);
+        }
+        g_prof.recs[k].clear();
+    }
+}
+}  // namespace
+
+ProfScope::ProfScope(int kind_, hipStream_t st_, double flops_, double bytes_)
+    : kind(kind_), st(st_), flops(flops_), bytes(bytes_) {
+    if (!g_prof.on) return;
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    e0 = get_event();
+    e1 = get_event();
+    if (e0) (void)hipEventRecord(e0, st);
+}
+ProfScope::~ProfScope() {
+    if (!e0 || !e1) return;
+    (void)hipEventRecord(e1, st);
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    g_prof.recs[kind].push_back(ProfRec{e0, e1, flops, bytes});
+}
+
+}  // namespace sei
+
+using namespace sei;
+
+static void free_level(Level *l) {
+    pool_free(l->coords);
+    pool_free(l->ht.keys);
+    pool_free(l->ht.vals);
+    delete l;
+}
+
+extern "C" {
+
+const char *sei_last_error(void) { return g_error.c_str(); }
+int sei_abi_version(void) { return 1; }
+
+int sei_metadata_create(sei_metadata_t **out) {
+    if (!out) SEI_FAIL("sei_metadata_create: null out");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        (void)hipGetLastError();
+        SEI_FAIL("sparseeventid_amd: no HIP device available (this engine has no CPU fallback)");
+    }
+    *out = new sei_metadata();
+    return 0;
+}
+
+void sei_metadata_destroy(sei_metadata_t *m) {
+    if (!m) return;
+    for (auto *rb : m->rulebooks) {
+        free_tiled(rb->fwd);
+        if (!rb->submanifold) free_tiled(rb->bwd);
+        delete rb;
+    }
+    for (auto *l : m->levels) free_level(l);
+    pool_free(m->input_row);
+    pool_free(m->row_first);
+    pool_free(m->row_last);
+    pool_free(m->row_count);
+    delete m;
+}
+
+int sei_input_build(sei_metadata_t *m, const int32_t *coords_dev, int64_t n, const int32_t spatial[3],
+                    int32_t batch_size, int32_t mode, sei_stream_t stream, int64_t *n_rows) {
+    if (!m || !n_rows || (n > 0 && !coords_dev)) SEI_FAIL("sei_input_build: null argument");
+    if (mode < 0 || mode > 4) SEI_FAIL("InputLayer: mode must be 0..4");
+    std::lock_guard<std::mutex> lk(m->mu);
+    if (!m->levels.empty()) SEI_FAIL("InputLayer: metadata already holds an input level");
+    m->input_mode = mode;
+    ProfScope ps(PROF_RULES, (hipStream_t)stream, 0.0, 12.0 * n);
+    return build_input_level(m, coords_dev, n, spatial, batch_size, (hipStream_t)stream, n_rows);
+}
+
+int sei_input_features_fwd(sei_metadata_t *m, const float *in, int32_t C, float *out, sei_stream_t stream) {
+    if (!m) SEI_FAIL("null metadata");
+    return input_features_fwd(m, in, C, out, (hipStream_t)stream);
+}
+int sei_input_features_bwd(sei_metadata_t *m, const float *dout, int32_t C, float *din, sei_stream_t stream) {
+    if (!m) SEI_FAIL("null metadata");
+    return input_features_bwd(m, dout, C, din, (hipStream_t)stream);
+}
+
+int sei_level_rows(sei_metadata_t *m, const int32_t spatial[3], int64_t *n_rows) {
+    std::lock_guard<std::mutex> lk(m->mu);
+    Level *l = find_level(m, spatial);
+    if (!l) SEI_FAIL("no level with this spatial size in the metadata");
+    *n_rows = l->n;
+    return 0;
+}
+
+int sei_level_coords(sei_metadata_t *m, const int32_t spatial[3], int32_t *coords_out_dev, sei_stream_t stream) {
+    std::lock_guard<std::mutex> lk(m->mu);
+    Level *l = find_level(m, spatial);
+    if (!l) SEI_FAIL("no level with this spatial size in the metadata");
+    if (l->n)
+        SEI_HIP(hipMemcpyAsync(coords_out_dev, l->coords, (size_t)l->n * 4 * sizeof(int32_t), hipMemcpyDeviceToDevice,
+                               (hipStream_t)stream));
+    return 0;
+}
+
+int sei_batch_size(sei_metadata_t *m, int32_t *batch_size) {
+    *batch_size = m->batch_size;
+    return 0;
+}
+
+static bool same3(const int32_t *a, const int32_t *b) { return a[0] == b[0] && a[1] == b[1] && a[2] == b[2]; }
+
+int sei_subm_rulebook(sei_metadata_t *m, const int32_t spatial[3], const int32_t filter[3], sei_stream_t stream,
+                      sei_rulebook_t **rb_out) {
+    std::lock_guard<std::mutex> lk(m->mu);
+    for (auto *rb : m->rulebooks)
+        if (rb->submanifold && same3(rb->spatial_in, spatial) && same3(rb->size, filter)) {
+            *rb_out = rb;
+            return 0;
+        }
+    Level *l = find_level(m, spatial);
+    if (!l) SEI_FAIL("SubmanifoldConvolution: no level with this spatial size in the metadata");
+    for (int d = 0; d < 3; d++)
+        if (filter[d] < 1 || filter[d] % 2 == 0) SEI_FAIL("SubmanifoldConvolution: filter sizes must be odd");
+    sei_rulebook *rb = new sei_rulebook();
+    rb->submanifold = true;
+    for (int d = 0; d < 3; d++) {
+        rb->spatial_in[d] = rb->spatial_out[d] = spatial[d];
+        rb->size[d] = filter[d];
+        rb->stride[d] = 1;
+    }
+    int rc = build_subm_rules(l, filter, &rb->fwd, (hipStream_t)stream);
+    if (rc) {
+        delete rb;
+        return rc;
+    }
+    m->rulebooks.push_back(rb);
+    *rb_out = rb;
+    return 0;
+}
+
+int sei_conv_rulebook(sei_metadata_t *m, const int32_t spatial_in[3], const int32_t size[3], const int32_t stride[3],
+                      sei_stream_t stream, sei_rulebook_t **rb_out, int32_t spatial_out[3]) {
+    std::lock_guard<std::mutex> lk(m->mu);
+    for (auto *rb : m->rulebooks)
+        if (!rb->submanifold && same3(rb->spatial_in, spatial_in) && same3(rb->size, size) && same3(rb->stride, stride)) {
+            *rb_out = rb;
+            for (int d = 0; d < 3; d++) spatial_out[d] = rb->spatial_out[d];
+            return 0;
+        }
+    Level *l = find_level(m, spatial_in);
+    if (!l) SEI_FAIL("Convolution: no level with this spatial size in the metadata");
+    sei_rulebook *rb = new sei_rulebook();
+    rb->submanifold = false;
+    for (int d = 0; d < 3; d++) {
+        rb->spatial_in[d] = spatial_in[d];
+        rb->size[d] = size[d];
+        rb->stride[d] = stride[d];
+    }
+    int rc = build_strided(m, l, size, stride, m->batch_size, rb, (hipStream_t)stream);
+    if (rc) {
+        delete rb;
+        return rc;
+    }
+    m->rulebooks.push_back(rb);
+    *rb_out = rb;
+    for (int d = 0; d < 3; d++) spatial_out[d] = rb->spatial_out[d];
+    return 0;
+}
+
+int sei_rulebook_info(const sei_rulebook_t *rb, int64_t info[6]) {
+    info[0] = rb->fwd.n_dst; info[1] = rb->fwd.n_src; info[2] = rb->fwd.K;
+    info[3] = rb->fwd.n_rules; info[4] = rb->fwd.n_chunks; info[5] = rb->fwd.n_tiles;
+    return 0;
+}
+
+int sei_rulebook_export(sei_rulebook_t *rb, int64_t *start_host, int32_t *rules_in_dev, int32_t *rules_out_dev,
+                        sei_stream_t stream) {
+    return export_rules(rb->fwd, start_host, rules_in_dev, rules_out_dev, (hipStream_t)stream);
+}
+
+static double conv_bytes(const TiledRules &t, int nIn, int nOut) {
+    return 4.0 * t.n_src * nIn + 4.0 * t.n_dst * nOut + 8.0 * t.n_rules + 4.0 * t.K * nIn * nOut;
+}
+
+int sei_conv_forward(sei_rulebook_t *rb, const float *X, const float *W, const float *bias, float *Y, int32_t nIn,
+                     int32_t nOut, sei_stream_t stream) {
+    if (!rb) SEI_FAIL("null rulebook");
+    const TiledRules &t = rb->fwd;
+    ProfScope ps(PROF_CONV_FWD, (hipStream_t)stream, 2.0 * t.n_rules * nIn * nOut, conv_bytes(t, nIn, nOut));
+    return conv_forward(t, false, X, W, bias, Y, nIn, nOut, (hipStream_t)stream);
+}
+
+int sei_conv_backward_input(sei_rulebook_t *rb, const float *dY, const float *W, float *dX, int32_t nIn, int32_t nOut,
+                            sei_stream_t stream) {
+    if (!rb) SEI_FAIL("null rulebook");
+    hipStream_t st = (hipStream_t)stream;
+    const TiledRules &t = rb->submanifold ? rb->fwd : rb->bwd;
+    ProfScope ps(PROF_CONV_BWD_IN, st, 2.0 * t.n_rules * nIn * nOut, conv_bytes(t, nOut, nIn));
+    float *Wt;
+    SEI_TRY(pool_alloc_t(&Wt, (size_t)t.K * nIn * nOut));
+    int rc = conv_transform_weights(W, Wt, t.K, nIn, nOut, rb->submanifold, st);
+    // roles swap: contraction over nOut, result has nIn columns
+    if (!rc) rc = conv_forward(t, false, dY, Wt, nullptr, dX, nOut, nIn, st);
+    pool_free(Wt);
+    return rc;
+}
+
+int sei_conv_backward_weight(sei_rulebook_t *rb, const float *X, const float *dY, float *dW, float *dbias, int32_t nIn,
+                             int32_t nOut, sei_stream_t stream) {
+    if (!rb) SEI_FAIL("null rulebook");
+    hipStream_t st = (hipStream_t)stream;
+    const TiledRules &t = rb->fwd;
+    {
+        ProfScope ps(PROF_CONV_BWD_W, st, 2.0 * t.n_rules * nIn * nOut,
+                     4.0 * t.n_src * nIn + 4.0 * t.n_dst * nOut + 8.0 * t.n_rules + 4.0 * t.K * nIn * nOut);
+        SEI_TRY(conv_backward_weight(t, X, dY, dW, nIn, nOut, st));
+    }
+    if (dbias) SEI_TRY(colsum(dY, t.n_dst, nOut, dbias, st));
+    return 0;
+}
+
+int sei_bn_forward(const float *x, int64_t n, int32_t C, const float *gamma, const float *beta, float *running_mean,
+                   float *running_var, float eps, float momentum, int32_t training, float leak, const float *residual,
+                   float *y, float *save_mean, float *save_invstd, sei_stream_t stream) {
+    return bn_forward(x, n, C, gamma, beta, running_mean, running_var, eps, momentum, training, leak, residual, y,
+                      save_mean, save_invstd, (hipStream_t)stream);
+}
+
+int sei_bn_backward(const float *x, const float *y, const float *dy, int64_t n, int32_t C, const float *gamma,
+                    const float *save_mean, const float *save_invstd, float leak, int32_t training, float *dx,
+                    float *dresidual, float *dgamma, float *dbeta, sei_stream_t stream) {
+    return bn_backward(x, y, dy, n, C, gamma, save_mean, save_invstd, leak, training, dx, dresidual, dgamma, dbeta,
+                       (hipStream_t)stream);
+}
+
+int sei_leaky_forward(const float *x, float *y, int64_t count, float leak, sei_stream_t stream) {
+    return leaky_forward(x, y, count, leak, (hipStream_t)stream);
+}
+int sei_leaky_backward(const float *y, const float *dy, float *dx, int64_t count, float leak, sei_stream_t stream) {
+    return leaky_backward(y, dy, dx, count, leak, (hipStream_t)stream);
+}
+int sei_add_forward(const float *a, const float *b, float *out, int64_t count, sei_stream_t stream) {
+    return add_forward(a, b, out, count, 1.f, false, (hipStream_t)stream);
+}
+int sei_add_leaky_forward(const float *a, const float *b, float *y, int64_t count, float leak, sei_stream_t stream) {
+    return add_forward(a, b, y, count, leak, true, (hipStream_t)stream);
+}
+
+int sei_sparse_to_dense_forward(sei_metadata_t *m, const int32_t spatial[3], const float *feats, int32_t C, float *dense,
+                                sei_stream_t stream) {
+    std::lock_guard<std::mutex> lk(m->mu);
+    Level *l = find_level(m, spatial);
+    if (!l) SEI_FAIL("SparseToDense: no level with this spatial size in the metadata");
+    return sparse_to_dense(l, m->batch_size, feats, C, dense, false, (hipStream_t)stream);
+}
+int sei_sparse_to_dense_backward(sei_metadata_t *m, const int32_t spatial[3], const float *ddense, int32_t C,
+                                 float *dfeats, sei_stream_t stream) {
+    std::lock_guard<std::mutex> lk(m->mu);
+    Level *l = find_level(m, spatial);
+    if (!l) SEI_FAIL("SparseToDense: no level with this spatial size in the metadata");
+    return sparse_to_dense(l, m->batch_size, dfeats, C, const_cast<float *>(ddense), true, (hipStream_t)stream);
+}
+
+int sei_prof_enable(int32_t on) {
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    g_prof.on = on != 0;
+    return 0;
+}
+int sei_prof_reset(void) {
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    drain_locked();
+    for (int k = 0; k < PROF_NKIND; k++) g_prof.ms[k] = g_prof.flops[k] = g_prof.bytes[k] = g_prof.launches[k] = 0;
+    return 0;
+}
+int sei_prof_query(int32_t kind, double out[4]) {
+    if (kind < 0 || kind >= PROF_NKIND) SEI_FAIL("sei_prof_query: bad kind");
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    drain_locked();
+    out[0] = g_prof.launches[kind]; out[1] = g_prof.ms[kind]; out[2] = g_prof.flops[kind]; out[3] = g_prof.bytes[kind];
+    return 0;
+}
+
+int sei_pool_stats(int64_t *bytes_held, int64_t *bytes_in_use) {
+    std::lock_guard<std::mutex> lk(g_pool.mu);
+    if (bytes_held) *bytes_held = (int64_t)g_pool.held;
+    if (bytes_in_use) *bytes_in_use = (int64_t)g_pool.in_use;
+    return 0;
+}
+int sei_pool_trim(void) {
+    std::lock_guard<std::mutex> lk(g_pool.mu);
+    for (auto &kv : g_pool.free_blocks) {
+        (void)hipFree(kv.second);
+        g_pool.held -= kv.first;
+    }
+    g_pool.free_blocks.clear();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,173 @@
+// Internal declarations shared by the HIP translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/sparseeventid_amd.h"
+
+namespace sei {
+
+// ---------------------------------------------------------------- errors
+void set_error(const std::string &msg);
+#define SEI_HIP(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            sei::set_error(std::string(#expr) + ": " + hipGetErrorString(_e) + " at " +       \
+                           __FILE__ + ":" + std::to_string(__LINE__));                        \
+            return 1;                                                                         \
+        }                                                                                     \
+    } while (0)
+#define SEI_FAIL(msg)            \
+    do {                         \
+        sei::set_error(msg);     \
+        return 1;                \
+    } while (0)
+#define SEI_TRY(expr)            \
+    do {                         \
+        int _r = (expr);         \
+        if (_r) return _r;       \
+    } while (0)
+#define SEI_LAUNCH_CHECK() SEI_HIP(hipGetLastError())
+
+// ---------------------------------------------------------------- device memory pool
+// Library-owned memory (hash tables, rulebooks, scratch).  Blocks are recycled on free so
+// the steady state of a training loop performs no hipMalloc.  All users enqueue on one
+// stream (torch's current stream), so reuse is stream-ordered.
+void *pool_alloc(size_t bytes);
+void pool_free(void *p);
+template <typename T>
+inline int pool_alloc_t(T **out, size_t count) {
+    *out = (T *)pool_alloc(count * sizeof(T) + 16);
+    if (!*out) {
+        set_error("device pool: out of memory");
+        return 1;
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------- hashing (device + host identical)
+constexpr uint64_t EMPTY_KEY = 0xFFFFFFFFFFFFFFFFull;
+__host__ __device__ inline uint64_t pack_key(int x0, int x1, int x2, int b) {
+    return ((uint64_t)(uint16_t)b << 48) | ((uint64_t)(uint16_t)x0 << 32) | ((uint64_t)(uint16_t)x1 << 16) |
+           (uint64_t)(uint16_t)x2;
+}
+__host__ __device__ inline uint64_t mix64(uint64_t k) {
+    k ^= k >> 33;
+    k *= 0xff51afd7ed558ccdull;
+    k ^= k >> 33;
+    k *= 0xc4ceb9fe1a85ec53ull;
+    k ^= k >> 33;
+    return k;
+}
+
+struct HashTable {
+    uint64_t *keys = nullptr;
+    uint32_t *vals = nullptr;
+    uint64_t mask = 0;
+};
+
+// One resolution level: active sites of one spatial size.
+struct Level {
+    int32_t spatial[3] = {0, 0, 0};
+    int64_t n = 0;
+    int32_t *coords = nullptr;  // [n,4] device
+    HashTable ht;
+};
+
+// ---------------------------------------------------------------- rulebook
+constexpr int TILE_ROWS = 64;    // dst rows per wave-tile (one lane per row while building)
+constexpr int CHUNK_SLOTS = 32;  // rule slots per chunk = two MFMA sub-chunks of 16 rules
+
+// Rules organised for output-stationary execution: dst rows are cut into wave-tiles of 64
+// consecutive rows; within a tile the rules are grouped by filter offset k and padded to
+// chunks of 32 slots (src = -1 marks padding).  One wavefront owns one tile.
+struct TiledRules {
+    int64_t n_dst = 0, n_src = 0;
+    int32_t K = 0;
+    int32_t n_tiles = 0;
+    int64_t n_chunks = 0;
+    int64_t n_rules = 0;
+    int64_t n_sub = 0;                    // non-empty 16-slot sub-chunks (executed MFMA row blocks)
+    int32_t *tile_chunk_start = nullptr;  // [n_tiles+1]
+    int32_t *chunk_src = nullptr;         // [n_chunks*32] src row or -1
+    uint8_t *chunk_dst = nullptr;         // [n_chunks*32] dst row local to tile
+    uint8_t *chunk_k = nullptr;           // [n_chunks]
+    int32_t *seg_start = nullptr;         // [(K+1)*n_tiles] k-major: first chunk (tile-relative) of offset k
+};
+void free_tiled(TiledRules &t);
+
+}  // namespace sei
+
+struct sei_rulebook {
+    sei::TiledRules fwd;      // dst = output rows, src = input rows
+    sei::TiledRules bwd;      // dst = input rows,  src = output rows (strided conv only)
+    bool submanifold = true;  // bwd == fwd with mirrored k
+    int32_t spatial_in[3], spatial_out[3], size[3], stride[3];
+};
+
+struct sei_metadata {
+    std::mutex mu;
+    int32_t batch_size = 0;
+    int32_t input_mode = 3;
+    int64_t n_input = 0;          // raw input points
+    int32_t *input_row = nullptr; // [n_input] row of each input point
+    int32_t *row_first = nullptr; // [n_rows] first input index of row
+    int32_t *row_last = nullptr;  // [n_rows]
+    int32_t *row_count = nullptr; // [n_rows]
+    std::vector<sei::Level *> levels;
+    std::vector<sei_rulebook *> rulebooks;
+};
+
+namespace sei {
+Level *find_level(sei_metadata *m, const int32_t spatial[3]);
+
+// ---- kernels' host launchers (one per translation unit) ----
+// hash.hip
+int alloc_table(HashTable *ht, int64_t n, hipStream_t st);
+int build_input_level(sei_metadata *m, const int32_t *coords, int64_t n, const int32_t spatial[3], int32_t batch,
+                      hipStream_t st, int64_t *n_rows);
+int input_features_fwd(sei_metadata *m, const float *in, int C, float *out, hipStream_t st);
+int input_features_bwd(sei_metadata *m, const float *dout, int C, float *din, hipStream_t st);
+int exclusive_scan_i32(const int32_t *in, int32_t *out, int64_t n, int32_t *total_dev, hipStream_t st);
+// rulebook.hip
+int build_subm_rules(Level *lv, const int32_t filter[3], TiledRules *out, hipStream_t st);
+int build_strided(sei_metadata *m, Level *lin, const int32_t size[3], const int32_t stride[3], int32_t batch,
+                  sei_rulebook *rb, hipStream_t st);
+int export_rules(const TiledRules &t, int64_t *start_host, int32_t *rin, int32_t *rout, hipStream_t st);
+// conv.hip
+int conv_forward(const TiledRules &t, bool flip_k, const float *X, const float *W, const float *bias, float *Y, int nIn,
+                 int nOut, hipStream_t st);
+int conv_transform_weights(const float *W, float *Wt, int K, int nIn, int nOut, bool flip, hipStream_t st);
+int conv_backward_weight(const TiledRules &t, const float *X, const float *dY, float *dW, int nIn, int nOut,
+                         hipStream_t st);
+// elementwise.hip
+int colsum(const float *x, int64_t n, int C, float *out, hipStream_t st);
+int bn_forward(const float *x, int64_t n, int C, const float *gamma, const float *beta, float *rmean, float *rvar,
+               float eps, float momentum, int training, float leak, const float *residual, float *y, float *save_mean,
+               float *save_invstd, hipStream_t st);
+int bn_backward(const float *x, const float *y, const float *dy, int64_t n, int C, const float *gamma,
+                const float *save_mean, const float *save_invstd, float leak, int training, float *dx, float *dres,
+                float *dgamma, float *dbeta, hipStream_t st);
+int leaky_forward(const float *x, float *y, int64_t count, float leak, hipStream_t st);
+int leaky_backward(const float *y, const float *dy, float *dx, int64_t count, float leak, hipStream_t st);
+int add_forward(const float *a, const float *b, float *out, int64_t count, float leak, bool act, hipStream_t st);
+int sparse_to_dense(const Level *lv, int batch, const float *feats, int C, float *dense, bool backward,
+                    hipStream_t st);
+
+// ---- profiling (HIP events around launches) ----
+enum ProfKind { PROF_CONV_FWD = 0, PROF_CONV_BWD_IN = 1, PROF_CONV_BWD_W = 2, PROF_RULES = 3, PROF_BN = 4, PROF_OTHER = 5, PROF_NKIND = 6 };
+struct ProfScope {
+    int kind;
+    hipStream_t st;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    double flops, bytes;
+    ProfScope(int kind, hipStream_t st, double flops, double bytes);
+    ~ProfScope();
+};
+}  // namespace sei

@@ -1,0 +1,414 @@
+// HBM-bound row-major [N,C] kernels: BatchNormalization (+fused LeakyReLU / residual add),
+// LeakyReLU, AddTable, SparseToDense  (sparse_building_blocks.py:39,80,96,122; resnet.py:124-125).
+// float4 per lane, per-channel reductions accumulated in fp64 and combined in a fixed order
+// (two-stage: per-block partials -> one finalize block), so results are run-to-run deterministic.
+#include "common.h"
+
+namespace sei {
+
+constexpr int RED_BLOCKS_MAX = 1024;
+
+// ------------------------------------------------------------------ column reductions
+// MODE 0: (x, x*x)                         -> BN statistics
+// MODE 1: (dz, dz*xhat), dz = dy*act'(y)   -> BN backward sums
+// MODE 2: (x, 0)                           -> bias gradient
+template <int MODE, int VEC>
+__global__ __launch_bounds__(256) void colreduce_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                        const float *__restrict__ dy, int64_t n, int C,
+                                                        const float *__restrict__ mean,
+                                                        const float *__restrict__ invstd, float leak,
+                                                        double *__restrict__ partial /*[blocks][2][C]*/) {
+    extern __shared__ double lds_d[];  // [rl][2][C]
+    const int cv = C / VEC;            // column groups
+    const int rl = 256 / cv;           // row lanes
+    const int col = threadIdx.x % cv, rlane = threadIdx.x / cv;
+    double s0[VEC], s1[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; v++) s0[v] = s1[v] = 0.0;
+    if (rlane < rl) {
+        float mu[VEC], is[VEC];
+        if (MODE == 1) {
+#pragma unroll
+            for (int v = 0; v < VEC; v++) {
+                mu[v] = mean[col * VEC + v];
+                is[v] = invstd[col * VEC + v];
+            }
+        }
+        const int64_t rows_per_block = (n + gridDim.x - 1) / gridDim.x;
+        const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+        const int64_t r1 = r0 + rows_per_block < n ? r0 + rows_per_block : n;
+        for (int64_t r = r0 + rlane; r < r1; r += rl) {
+            float xv[VEC], yv[VEC], dv[VEC];
+            const size_t off = (size_t)r * C + col * VEC;
+            if (VEC == 4) {
+                float4 t = *reinterpret_cast<const float4 *>(x + off);
+                xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
+                if (MODE == 1) {
+                    float4 u = *reinterpret_cast<const float4 *>(y + off);
+                    yv[0] = u.x; yv[1] = u.y; yv[2] = u.z; yv[3] = u.w;
+                    float4 w = *reinterpret_cast<const float4 *>(dy + off);
+                    dv[0] = w.x; dv[1] = w.y; dv[2] = w.z; dv[3] = w.w;
+                }
+            } else {
+                xv[0] = x[off];
+                if (MODE == 1) {
+                    yv[0] = y[off];
+                    dv[0] = dy[off];
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < VEC; v++) {
+                if (MODE == 0) {
+                    double d = (double)xv[v];
+                    s0[v] += d;
+                    s1[v] += d * d;
+                } else if (MODE == 1) {
+                    float dz = yv[v] > 0.f ? dv[v] : dv[v] * leak;
+                    float xh = (xv[v] - mu[v]) * is[v];
+                    s0[v] += (double)dz;
+                    s1[v] += (double)dz * (double)xh;
+                } else {
+                    s0[v] += (double)xv[v];
+                }
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; v++) {
+            lds_d[(rlane * 2 + 0) * C + col * VEC + v] = s0[v];
+            lds_d[(rlane * 2 + 1) * C + col * VEC + v] = s1[v];
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * C; e += 256) {
+        double acc = 0.0;
+        for (int q = 0; q < rl; q++) acc += lds_d[q * 2 * C + e];
+        partial[(size_t)blockIdx.x * 2 * C + e] = acc;
+    }
+}
+
+// finalize kinds
+//  0: BN stats -> save_mean, save_invstd, running update
+//  1: BN backward -> coef[0][C]=sum_dz/n, coef[1][C]=sum_dzxhat/n ; dgamma, dbeta
+//  2: colsum -> out[C]
+__global__ void finalize_kernel(const double *__restrict__ partial, int blocks, int C, int64_t n, int kind,
+                                float eps, float momentum, float *a0, float *a1, float *a2, float *a3) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s0 = 0.0, s1 = 0.0;
+    for (int b = 0; b < blocks; b++) {
+        s0 += partial[(size_t)b * 2 * C + c];
+        s1 += partial[(size_t)b * 2 * C + C + c];
+    }
+    if (kind == 0) {
+        double mean = s0 / (double)n;
+        double var = s1 / (double)n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        a0[c] = (float)mean;                          // save_mean
+        a1[c] = (float)(1.0 / sqrt(var + (double)eps));  // save_invstd
+        if (a2) {                                     // running stats (SCN: r = m*r + (1-m)*batch, unbiased var)
+            double unb = n > 1 ? var * (double)n / (double)(n - 1) : var;
+            a2[c] = momentum * a2[c] + (1.f - momentum) * (float)mean;
+            a3[c] = momentum * a3[c] + (1.f - momentum) * (float)unb;
+        }
+    } else if (kind == 1) {
+        a0[c] = (float)(s0 / (double)n);
+        a1[c] = (float)(s1 / (double)n);
+        if (a2) a2[c] = (float)s1;  // dgamma
+        if (a3) a3[c] = (float)s0;  // dbeta
+    } else {
+        a0[c] = (float)s0;
+    }
+}
+
+static int reduce_launch(int mode, const float *x, const float *y, const float *dy, int64_t n, int C, const float *mean,
+                         const float *invstd, float leak, double **partial_out, int *blocks_out, hipStream_t st) {
+    int vec = (C % 4 == 0) ? 4 : 1;
+    int cv = C / vec;
+    if (cv > 256) SEI_FAIL("channel count too large for the reduction kernel (max 1024 with C%4==0, else 256)");
+    int rl = 256 / cv;
+    int64_t want = (n + (int64_t)rl * 8 - 1) / ((int64_t)rl * 8);
+    int blocks = (int)(want < 1 ? 1 : (want > RED_BLOCKS_MAX ? RED_BLOCKS_MAX : want));
+    double *partial;
+    SEI_TRY(pool_alloc_t(&partial, (size_t)blocks * 2 * C));
+    size_t lds = (size_t)rl * 2 * C * sizeof(double);
+#define RL(MODE, VEC) colreduce_kernel<MODE, VEC><<<blocks, 256, lds, st>>>(x, y, dy, n, C, mean, invstd, leak, partial)
+    if (vec == 4) {
+        if (mode == 0) RL(0, 4); else if (mode == 1) RL(1, 4); else RL(2, 4);
+    } else {
+        if (mode == 0) RL(0, 1); else if (mode == 1) RL(1, 1); else RL(2, 1);
+    }
+#undef RL
+    SEI_LAUNCH_CHECK();
+    *partial_out = partial;
+    *blocks_out = blocks;
+    return 0;
+}
+
+int colsum(const float *x, int64_t n, int C, float *out, hipStream_t st) {
+    if (n == 0) {
+        SEI_HIP(hipMemsetAsync(out, 0, C * sizeof(float), st));
+        return 0;
+    }
+    double *partial;
+    int blocks;
+    SEI_TRY(reduce_launch(2, x, nullptr, nullptr, n, C, nullptr, nullptr, 1.f, &partial, &blocks, st));
+    finalize_kernel<<<(C + 63) / 64, 64, 0, st>>>(partial, blocks, C, n, 2, 0.f, 0.f, out, nullptr, nullptr, nullptr);
+    SEI_LAUNCH_CHECK();
+    pool_free(partial);
+    return 0;
+}
+
+// ------------------------------------------------------------------ BN apply
+template <int VEC>
+__global__ void bn_apply_kernel(const float *__restrict__ x, const float *__restrict__ res, float *__restrict__ y,
+                                int64_t total_vec, int C, const float *__restrict__ mean,
+                                const float *__restrict__ invstd, const float *__restrict__ gamma,
+                                const float *__restrict__ beta, float leak) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; t < total_vec; t += stride) {
+        int c = (int)((t * VEC) % C);
+        float xv[VEC], rv[VEC], o[VEC];
+        if (VEC == 4) {
+            float4 a = reinterpret_cast<const float4 *>(x)[t];
+            xv[0] = a.x; xv[1] = a.y; xv[2] = a.z; xv[3] = a.w;
+            if (res) {
+                float4 b = reinterpret_cast<const float4 *>(res)[t];
+                rv[0] = b.x; rv[1] = b.y; rv[2] = b.z; rv[3] = b.w;
+            }
+        } else {
+            xv[0] = x[t];
+            if (res) rv[0] = res[t];
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; v++) {
+            float g = gamma ? gamma[c + v] : 1.f, b = beta ? beta[c + v] : 0.f;
+            float z = (xv[v] - mean[c + v]) * (invstd[c + v] * g) + b;
+            if (res) z += rv[v];
+            o[v] = z > 0.f ? z : z * leak;
+        }
+        if (VEC == 4)
+            reinterpret_cast<float4 *>(y)[t] = make_float4(o[0], o[1], o[2], o[3]);
+        else
+            y[t] = o[0];
+    }
+}
+
+template <int VEC>
+__global__ void bn_bwd_apply_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                    const float *__restrict__ dy, float *__restrict__ dx, float *__restrict__ dres,
+                                    int64_t total_vec, int C, const float *__restrict__ mean,
+                                    const float *__restrict__ invstd, const float *__restrict__ gamma,
+                                    const float *__restrict__ coef /*[2][C] or null (eval)*/, float leak) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; t < total_vec; t += stride) {
+        int c = (int)((t * VEC) % C);
+        float xv[VEC], yv[VEC], dv[VEC], o[VEC], dz[VEC];
+        if (VEC == 4) {
+            float4 a = reinterpret_cast<const float4 *>(x)[t];
+            xv[0] = a.x; xv[1] = a.y; xv[2] = a.z; xv[3] = a.w;
+            float4 b = reinterpret_cast<const float4 *>(y)[t];
+            yv[0] = b.x; yv[1] = b.y; yv[2] = b.z; yv[3] = b.w;
+            float4 d = reinterpret_cast<const float4 *>(dy)[t];
+            dv[0] = d.x; dv[1] = d.y; dv[2] = d.z; dv[3] = d.w;
+        } else {
+            xv[0] = x[t]; yv[0] = y[t]; dv[0] = dy[t];
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; v++) {
+            dz[v] = yv[v] > 0.f ? dv[v] : dv[v] * leak;
+            float g = gamma ? gamma[c + v] : 1.f;
+            float is = invstd[c + v];
+            if (coef) {
+                float xh = (xv[v] - mean[c + v]) * is;
+                o[v] = g * is * (dz[v] - coef[c + v] - xh * coef[C + c + v]);
+            } else {
+                o[v] = g * is * dz[v];
+            }
+        }
+        if (VEC == 4) {
+            reinterpret_cast<float4 *>(dx)[t] = make_float4(o[0], o[1], o[2], o[3]);
+            if (dres) reinterpret_cast<float4 *>(dres)[t] = make_float4(dz[0], dz[1], dz[2], dz[3]);
+        } else {
+            dx[t] = o[0];
+            if (dres) dres[t] = dz[0];
+        }
+    }
+}
+
+__global__ void eval_stats_kernel(const float *rmean, const float *rvar, float eps, int C, float *save_mean,
+                                  float *save_invstd) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    save_mean[c] = rmean[c];
+    save_invstd[c] = 1.f / sqrtf(rvar[c] + eps);
+}
+
+static inline unsigned ew_blocks(int64_t total_vec) {
+    int64_t b = (total_vec + 255) / 256;
+    return (unsigned)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
+}
+
+int bn_forward(const float *x, int64_t n, int C, const float *gamma, const float *beta, float *rmean, float *rvar,
+               float eps, float momentum, int training, float leak, const float *residual, float *y, float *save_mean,
+               float *save_invstd, hipStream_t st) {
+    ProfScope ps(PROF_BN, st, 0.0, (residual ? 16.0 : 12.0) * (double)n * C);
+    if (training) {
+        if (n == 0) return 0;
+        double *partial;
+        int blocks;
+        SEI_TRY(reduce_launch(0, x, nullptr, nullptr, n, C, nullptr, nullptr, 1.f, &partial, &blocks, st));
+        finalize_kernel<<<(C + 63) / 64, 64, 0, st>>>(partial, blocks, C, n, 0, eps, momentum, save_mean, save_invstd,
+                                                      rmean, rvar);
+        SEI_LAUNCH_CHECK();
+        pool_free(partial);
+    } else {
+        if (!rmean || !rvar) SEI_FAIL("BatchNormalization eval mode needs running statistics");
+        eval_stats_kernel<<<(C + 63) / 64, 64, 0, st>>>(rmean, rvar, eps, C, save_mean, save_invstd);
+        SEI_LAUNCH_CHECK();
+        if (n == 0) return 0;
+    }
+    if (C % 4 == 0) {
+        int64_t tv = n * C / 4;
+        bn_apply_kernel<4><<<ew_blocks(tv), 256, 0, st>>>(x, residual, y, tv, C, save_mean, save_invstd, gamma, beta, leak);
+    } else {
+        int64_t tv = n * C;
+        bn_apply_kernel<1><<<ew_blocks(tv), 256, 0, st>>>(x, residual, y, tv, C, save_mean, save_invstd, gamma, beta, leak);
+    }
+    SEI_LAUNCH_CHECK();
+    return 0;
+}
+
+int bn_backward(const float *x, const float *y, const float *dy, int64_t n, int C, const float *gamma,
+                const float *save_mean, const float *save_invstd, float leak, int training, float *dx, float *dres,
+                float *dgamma, float *dbeta, hipStream_t st) {
+    ProfScope ps(PROF_BN, st, 0.0, (dres ? 32.0 : 28.0) * (double)n * C);
+    if (n == 0) {
+        if (dgamma) SEI_HIP(hipMemsetAsync(dgamma, 0, C * sizeof(float), st));
+        if (dbeta) SEI_HIP(hipMemsetAsync(dbeta, 0, C * sizeof(float), st));
+        return 0;
+    }
+    float *coef;
+    SEI_TRY(pool_alloc_t(&coef, 2 * C));
+    double *partial;
+    int blocks;
+    SEI_TRY(reduce_launch(1, x, y, dy, n, C, save_mean, save_invstd, leak, &partial, &blocks, st));
+    finalize_kernel<<<(C + 63) / 64, 64, 0, st>>>(partial, blocks, C, n, 1, 0.f, 0.f, coef, coef + C, dgamma, dbeta);
+    SEI_LAUNCH_CHECK();
+    pool_free(partial);
+    const float *cf = training ? coef : nullptr;
+    if (C % 4 == 0) {
+        int64_t tv = n * C / 4;
+        bn_bwd_apply_kernel<4><<<ew_blocks(tv), 256, 0, st>>>(x, y, dy, dx, dres, tv, C, save_mean, save_invstd, gamma, cf, leak);
+    } else {
+        int64_t tv = n * C;
+        bn_bwd_apply_kernel<1><<<ew_blocks(tv), 256, 0, st>>>(x, y, dy, dx, dres, tv, C, save_mean, save_invstd, gamma, cf, leak);
+    }
+    SEI_LAUNCH_CHECK();
+    pool_free(coef);
+    return 0;
+}
+
+// ------------------------------------------------------------------ LeakyReLU / AddTable
+__global__ void leaky_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, int64_t n4, int64_t count, float leak) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = t; i < n4; i += stride) {
+        float4 a = reinterpret_cast<const float4 *>(x)[i];
+        a.x = a.x > 0.f ? a.x : a.x * leak; a.y = a.y > 0.f ? a.y : a.y * leak;
+        a.z = a.z > 0.f ? a.z : a.z * leak; a.w = a.w > 0.f ? a.w : a.w * leak;
+        reinterpret_cast<float4 *>(y)[i] = a;
+    }
+    for (int64_t i = n4 * 4 + t; i < count; i += stride) y[i] = x[i] > 0.f ? x[i] : x[i] * leak;
+}
+
+__global__ void leaky_bwd_kernel(const float *__restrict__ y, const float *__restrict__ dy, float *__restrict__ dx,
+                                 int64_t n4, int64_t count, float leak) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = t; i < n4; i += stride) {
+        float4 a = reinterpret_cast<const float4 *>(y)[i];
+        float4 d = reinterpret_cast<const float4 *>(dy)[i];
+        d.x = a.x > 0.f ? d.x : d.x * leak; d.y = a.y > 0.f ? d.y : d.y * leak;
+        d.z = a.z > 0.f ? d.z : d.z * leak; d.w = a.w > 0.f ? d.w : d.w * leak;
+        reinterpret_cast<float4 *>(dx)[i] = d;
+    }
+    for (int64_t i = n4 * 4 + t; i < count; i += stride) dx[i] = y[i] > 0.f ? dy[i] : dy[i] * leak;
+}
+
+__global__ void add_kernel(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ o, int64_t n4,
+                           int64_t count, float leak, int act) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = t; i < n4; i += stride) {
+        float4 u = reinterpret_cast<const float4 *>(a)[i];
+        float4 v = reinterpret_cast<const float4 *>(b)[i];
+        u.x += v.x; u.y += v.y; u.z += v.z; u.w += v.w;
+        if (act) {
+            u.x = u.x > 0.f ? u.x : u.x * leak; u.y = u.y > 0.f ? u.y : u.y * leak;
+            u.z = u.z > 0.f ? u.z : u.z * leak; u.w = u.w > 0.f ? u.w : u.w * leak;
+        }
+        reinterpret_cast<float4 *>(o)[i] = u;
+    }
+    for (int64_t i = n4 * 4 + t; i < count; i += stride) {
+        float s = a[i] + b[i];
+        o[i] = (act && s <= 0.f) ? s * leak : s;
+    }
+}
+
+int leaky_forward(const float *x, float *y, int64_t count, float leak, hipStream_t st) {
+    if (count == 0) return 0;
+    int64_t n4 = ((uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0) ? count / 4 : 0;
+    leaky_fwd_kernel<<<ew_blocks(count / 4 + 1), 256, 0, st>>>(x, y, n4, count, leak);
+    SEI_LAUNCH_CHECK();
+    return 0;
+}
+int leaky_backward(const float *y, const float *dy, float *dx, int64_t count, float leak, hipStream_t st) {
+    if (count == 0) return 0;
+    int64_t n4 = ((uintptr_t)y % 16 == 0 && (uintptr_t)dy % 16 == 0 && (uintptr_t)dx % 16 == 0) ? count / 4 : 0;
+    leaky_bwd_kernel<<<ew_blocks(count / 4 + 1), 256, 0, st>>>(y, dy, dx, n4, count, leak);
+    SEI_LAUNCH_CHECK();
+    return 0;
+}
+int add_forward(const float *a, const float *b, float *out, int64_t count, float leak, bool act, hipStream_t st) {
+    if (count == 0) return 0;
+    int64_t n4 = ((uintptr_t)a % 16 == 0 && (uintptr_t)b % 16 == 0 && (uintptr_t)out % 16 == 0) ? count / 4 : 0;
+    add_kernel<<<ew_blocks(count / 4 + 1), 256, 0, st>>>(a, b, out, n4, count, leak, act ? 1 : 0);
+    SEI_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------ SparseToDense
+// dense [B, C, D0, D1, D2]; thread per (row, channel) with channel fastest across lanes of a
+// row group so the feature read is coalesced (the dense side is a 4-byte scatter by nature).
+__global__ void sparse_to_dense_kernel(const int32_t *__restrict__ coords, int64_t n, int C, int D0, int D1, int D2,
+                                       const float *__restrict__ feats, float *__restrict__ dense, int backward,
+                                       float *__restrict__ dfeats) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * C) return;
+    int64_t r = t / C;
+    int c = (int)(t - r * C);
+    int4 p = reinterpret_cast<const int4 *>(coords)[r];
+    size_t vol = (size_t)D0 * D1 * D2;
+    size_t off = ((size_t)p.w * C + c) * vol + ((size_t)p.x * D1 + p.y) * D2 + p.z;
+    if (backward)
+        dfeats[t] = dense[off];
+    else
+        dense[off] = feats[t];
+}
+
+int sparse_to_dense(const Level *lv, int batch, const float *feats, int C, float *dense, bool backward,
+                    hipStream_t st) {
+    size_t vol = (size_t)lv->spatial[0] * lv->spatial[1] * lv->spatial[2];
+    if (!backward) SEI_HIP(hipMemsetAsync(dense, 0, (size_t)batch * C * vol * sizeof(float), st));
+    if (lv->n == 0) return 0;
+    int64_t tot = lv->n * C;
+    sparse_to_dense_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, st>>>(
+        lv->coords, lv->n, C, lv->spatial[0], lv->spatial[1], lv->spatial[2], feats, dense, backward ? 1 : 0,
+        const_cast<float *>(feats));
+    SEI_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace sei

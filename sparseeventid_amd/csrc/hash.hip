@@ -1,0 +1,310 @@
+// Coordinate hash tables on the device + scn.InputLayer (resnet.py:40-43,143).
+// Open addressing, linear probing, 64-bit packed keys (batch|x0|x1|x2), load factor <= 0.5.
+// HBM/MALL-bound integer work: one thread per point, coalesced reads of the COO array.
+#include "common.h"
+
+namespace sei {
+
+// ------------------------------------------------------------------ exclusive scan (int32)
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_BLOCK = SCAN_THREADS * SCAN_ITEMS;
+
+__device__ inline int block_exclusive_scan(int v, int *total, int *lds /*[SCAN_THREADS/64+1]*/) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
+    }
+    if (lane == 63) lds[wave] = incl;
+    __syncthreads();
+    int base = 0, tot = 0;
+    const int nw = blockDim.x >> 6;
+    for (int w = 0; w < nw; w++) {
+        int s = lds[w];
+        if (w < wave) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + incl - v;
+}
+
+__global__ void scan_reduce_kernel(const int32_t *in, int64_t n, int32_t *block_sums) {
+    __shared__ int lds[8];
+    int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_ITEMS;
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++)
+        if (base + i < n) s += in[base + i];
+    int tot;
+    block_exclusive_scan(s, &tot, lds);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+
+__global__ void scan_blocksums_kernel(int32_t *block_sums, int nb, int32_t *total_out) {
+    __shared__ int lds[20];
+    int carry = 0;
+    for (int b0 = 0; b0 < nb; b0 += blockDim.x) {
+        int i = b0 + threadIdx.x;
+        int v = i < nb ? block_sums[i] : 0;
+        int tot;
+        int ex = block_exclusive_scan(v, &tot, lds);
+        if (i < nb) block_sums[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0 && total_out) *total_out = carry;
+}
+
+__global__ void scan_apply_kernel(const int32_t *in, int32_t *out, int64_t n, const int32_t *block_sums) {
+    __shared__ int lds[8];
+    int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_ITEMS;
+    int v[SCAN_ITEMS];
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        v[i] = base + i < n ? in[base + i] : 0;
+        s += v[i];
+    }
+    int tot;
+    int ex = block_exclusive_scan(s, &tot, lds) + block_sums[blockIdx.x];
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        if (base + i < n) out[base + i] = ex;
+        ex += v[i];
+    }
+}
+
+// out[i] = sum_{j<i} in[j]; *total_dev (device int, may be null) = sum of all.  in/out may alias.
+int exclusive_scan_i32(const int32_t *in, int32_t *out, int64_t n, int32_t *total_dev, hipStream_t st) {
+    if (n == 0) {
+        if (total_dev) SEI_HIP(hipMemsetAsync(total_dev, 0, sizeof(int32_t), st));
+        return 0;
+    }
+    int nb = (int)((n + SCAN_BLOCK - 1) / SCAN_BLOCK);
+    int32_t *bs;
+    SEI_TRY(pool_alloc_t(&bs, nb));
+    scan_reduce_kernel<<<nb, SCAN_THREADS, 0, st>>>(in, n, bs);
+    scan_blocksums_kernel<<<1, 1024, 0, st>>>(bs, nb, total_dev);
+    scan_apply_kernel<<<nb, SCAN_THREADS, 0, st>>>(in, out, n, bs);
+    SEI_LAUNCH_CHECK();
+    pool_free(bs);
+    return 0;
+}
+
+// ------------------------------------------------------------------ hash insert
+// Insert key; the slot's value becomes the MIN candidate id that hit it (deterministic
+// representative = first appearance).  Returns the slot.
+__device__ inline uint32_t hash_insert_min(uint64_t *keys, uint32_t *vals, uint64_t mask, uint64_t key, uint32_t cand) {
+    uint64_t s = mix64(key) & mask;
+    for (;;) {
+        unsigned long long prev = atomicCAS((unsigned long long *)&keys[s], (unsigned long long)EMPTY_KEY,
+                                            (unsigned long long)key);
+        if (prev == EMPTY_KEY || prev == key) {
+            atomicMin(&vals[s], cand);
+            return (uint32_t)s;
+        }
+        s = (s + 1) & mask;
+    }
+}
+
+__global__ void input_insert_kernel(const int32_t *__restrict__ coords, int64_t n, int s0, int s1, int s2, int batch,
+                                    uint64_t *keys, uint32_t *vals, uint64_t mask, uint32_t *slot_of, int32_t *err) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int4 c = reinterpret_cast<const int4 *>(coords)[i];
+    if (c.x < 0 || c.x >= s0 || c.y < 0 || c.y >= s1 || c.z < 0 || c.z >= s2 || c.w < 0 || c.w >= batch) {
+        atomicMin((unsigned int *)err, (unsigned int)i);
+        slot_of[i] = 0xFFFFFFFFu;
+        return;
+    }
+    slot_of[i] = hash_insert_min(keys, vals, mask, pack_key(c.x, c.y, c.z, c.w), (uint32_t)i);
+}
+
+__global__ void flag_first_kernel(const uint32_t *slot_of, const uint32_t *vals, int64_t n, int32_t *flag) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t s = slot_of[i];
+    flag[i] = (s != 0xFFFFFFFFu && vals[s] == (uint32_t)i) ? 1 : 0;
+}
+
+// representatives write their row's coords + first index; slot value is re-pointed to the row in a
+// second array so that concurrent readers of `vals` are not disturbed.
+__global__ void assign_rows_kernel(const int32_t *__restrict__ coords, const uint32_t *slot_of, const uint32_t *vals,
+                                   const int32_t *pos, int64_t n, int32_t *out_coords, uint32_t *new_vals,
+                                   int32_t *row_first) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t s = slot_of[i];
+    if (s == 0xFFFFFFFFu || vals[s] != (uint32_t)i) return;
+    int r = pos[i];
+    reinterpret_cast<int4 *>(out_coords)[r] = reinterpret_cast<const int4 *>(coords)[i];
+    new_vals[s] = (uint32_t)r;
+    row_first[r] = (int32_t)i;
+}
+
+__global__ void input_rowof_kernel(const uint32_t *slot_of, const uint32_t *new_vals, int64_t n, int32_t *input_row,
+                                   int32_t *row_last, int32_t *row_count) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t s = slot_of[i];
+    if (s == 0xFFFFFFFFu) {
+        input_row[i] = -1;
+        return;
+    }
+    int r = (int)new_vals[s];
+    input_row[i] = r;
+    atomicMax(&row_last[r], (int32_t)i);
+    atomicAdd(&row_count[r], 1);
+}
+
+static uint64_t table_capacity(int64_t n) {
+    uint64_t cap = 1024;
+    while (cap < (uint64_t)(2 * n + 1)) cap <<= 1;
+    return cap;
+}
+
+int alloc_table(HashTable *ht, int64_t n, hipStream_t st) {
+    uint64_t cap = table_capacity(n);
+    SEI_TRY(pool_alloc_t(&ht->keys, cap));
+    SEI_TRY(pool_alloc_t(&ht->vals, cap));
+    ht->mask = cap - 1;
+    SEI_HIP(hipMemsetAsync(ht->keys, 0xFF, cap * sizeof(uint64_t), st));
+    SEI_HIP(hipMemsetAsync(ht->vals, 0xFF, cap * sizeof(uint32_t), st));
+    return 0;
+}
+
+// scn.InputLayer coordinate pass.
+int build_input_level(sei_metadata *m, const int32_t *coords, int64_t n, const int32_t spatial[3], int32_t batch,
+                      hipStream_t st, int64_t *n_rows) {
+    for (int d = 0; d < 3; d++)
+        if (spatial[d] <= 0 || spatial[d] > 65535) SEI_FAIL("InputLayer: spatial size must be in [1,65535]");
+    if (batch <= 0 || batch > 65534) SEI_FAIL("InputLayer: batch size must be in [1,65534]");
+    if (n >= (1ll << 31) - 64) SEI_FAIL("InputLayer: too many points");
+    Level *lv = new Level();
+    for (int d = 0; d < 3; d++) lv->spatial[d] = spatial[d];
+    m->levels.push_back(lv);
+    m->batch_size = batch;
+    m->n_input = n;
+    if (n == 0) {
+        lv->n = 0;
+        SEI_TRY(alloc_table(&lv->ht, 0, st));
+        SEI_TRY(pool_alloc_t(&lv->coords, 4));
+        *n_rows = 0;
+        return 0;
+    }
+    SEI_TRY(alloc_table(&lv->ht, n, st));
+    uint32_t *slot_of, *new_vals;
+    int32_t *flag, *err_total;
+    SEI_TRY(pool_alloc_t(&slot_of, n));
+    SEI_TRY(pool_alloc_t(&flag, n));
+    SEI_TRY(pool_alloc_t(&err_total, 2));
+    SEI_TRY(pool_alloc_t(&new_vals, lv->ht.mask + 1));
+    SEI_TRY(pool_alloc_t(&m->input_row, n));
+    SEI_HIP(hipMemsetAsync(err_total, 0xFF, sizeof(int32_t), st));
+    SEI_HIP(hipMemsetAsync(new_vals, 0xFF, (lv->ht.mask + 1) * sizeof(uint32_t), st));
+    const int T = 256;
+    const int nb = (int)((n + T - 1) / T);
+    input_insert_kernel<<<nb, T, 0, st>>>(coords, n, spatial[0], spatial[1], spatial[2], batch, lv->ht.keys,
+                                          lv->ht.vals, lv->ht.mask, slot_of, err_total);
+    flag_first_kernel<<<nb, T, 0, st>>>(slot_of, lv->ht.vals, n, flag);
+    SEI_LAUNCH_CHECK();
+    SEI_TRY(exclusive_scan_i32(flag, flag, n, err_total + 1, st));
+    int32_t host[2];
+    SEI_HIP(hipMemcpyAsync(host, err_total, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    SEI_HIP(hipStreamSynchronize(st));
+    if (host[0] != -1) {
+        pool_free(slot_of); pool_free(flag); pool_free(err_total); pool_free(new_vals);
+        SEI_FAIL("InputLayer: coordinate of input point " + std::to_string((uint32_t)host[0]) +
+                 " is outside spatial_size / batch_size");
+    }
+    int64_t nr = host[1];
+    lv->n = nr;
+    SEI_TRY(pool_alloc_t(&lv->coords, 4 * nr));
+    SEI_TRY(pool_alloc_t(&m->row_first, nr));
+    SEI_TRY(pool_alloc_t(&m->row_last, nr));
+    SEI_TRY(pool_alloc_t(&m->row_count, nr));
+    SEI_HIP(hipMemsetAsync(m->row_last, 0xFF, nr * sizeof(int32_t), st));
+    SEI_HIP(hipMemsetAsync(m->row_count, 0, nr * sizeof(int32_t), st));
+    assign_rows_kernel<<<nb, T, 0, st>>>(coords, slot_of, lv->ht.vals, flag, n, lv->coords, new_vals, m->row_first);
+    input_rowof_kernel<<<nb, T, 0, st>>>(slot_of, new_vals, n, m->input_row, m->row_last, m->row_count);
+    SEI_LAUNCH_CHECK();
+    // the table now maps key -> row
+    pool_free(lv->ht.vals);
+    lv->ht.vals = new_vals;
+    pool_free(slot_of);
+    pool_free(flag);
+    pool_free(err_total);
+    *n_rows = nr;
+    return 0;
+}
+
+// ------------------------------------------------------------------ InputLayer features
+// mode 0/2: first, 1: last, 3: sum, 4: mean.  One thread per (point, channel).
+__global__ void input_feat_fwd_kernel(const float *__restrict__ in, int64_t n, int C, const int32_t *input_row,
+                                      const int32_t *row_first, const int32_t *row_last, const int32_t *row_count,
+                                      int mode, float *out) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * C) return;
+    int64_t i = t / C;
+    int c = (int)(t - i * C);
+    int r = input_row[i];
+    float v = in[t];
+    if (mode == 3 || mode == 4) {
+        int cnt = row_count[r];
+        if (mode == 4) v /= (float)cnt;
+        if (cnt == 1)
+            out[(int64_t)r * C + c] = v;
+        else
+            atomicAdd(&out[(int64_t)r * C + c], v);
+    } else if (mode == 1) {
+        if (row_last[r] == i) out[(int64_t)r * C + c] = v;
+    } else {
+        if (row_first[r] == i) out[(int64_t)r * C + c] = v;
+    }
+}
+
+__global__ void input_feat_bwd_kernel(const float *__restrict__ dout, int64_t n, int C, const int32_t *input_row,
+                                      const int32_t *row_first, const int32_t *row_last, const int32_t *row_count,
+                                      int mode, float *din) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * C) return;
+    int64_t i = t / C;
+    int c = (int)(t - i * C);
+    int r = input_row[i];
+    float g = dout[(int64_t)r * C + c];
+    if (mode == 4)
+        g /= (float)row_count[r];
+    else if (mode == 1)
+        g = row_last[r] == i ? g : 0.f;
+    else if (mode != 3)
+        g = row_first[r] == i ? g : 0.f;
+    din[t] = g;
+}
+
+int input_features_fwd(sei_metadata *m, const float *in, int C, float *out, hipStream_t st) {
+    if (m->levels.empty()) SEI_FAIL("InputLayer features: metadata has no input level");
+    int64_t nr = m->levels[0]->n, n = m->n_input;
+    if (nr == 0 || n == 0) return 0;
+    if (m->input_mode == 3 || m->input_mode == 4) SEI_HIP(hipMemsetAsync(out, 0, (size_t)nr * C * sizeof(float), st));
+    int64_t tot = n * C;
+    input_feat_fwd_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, st>>>(in, n, C, m->input_row, m->row_first,
+                                                                        m->row_last, m->row_count, m->input_mode, out);
+    SEI_LAUNCH_CHECK();
+    return 0;
+}
+
+int input_features_bwd(sei_metadata *m, const float *dout, int C, float *din, hipStream_t st) {
+    if (m->levels.empty()) SEI_FAIL("InputLayer features: metadata has no input level");
+    int64_t n = m->n_input;
+    if (n == 0) return 0;
+    int64_t tot = n * C;
+    input_feat_bwd_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, st>>>(dout, n, C, m->input_row, m->row_first,
+                                                                        m->row_last, m->row_count, m->input_mode, din);
+    SEI_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace sei

@@ -1,0 +1,568 @@
+"""Drop-in mirror of the ``sparseconvnet`` (scn) nn.Module surface used by the reference network
+(/root/reference/src/networks/resnet.py:26-50,105-110,124-125;
+ /root/reference/src/networks/sparse_building_blocks.py:20,29-34,39,76-82,110-117,122),
+backed by the hand-written gfx950 engine through the C ABI (include/sparseeventid_amd.h).
+
+Same constructor keywords, same parameter names / shapes (``weight [K,nIn,nOut]``, ``bias [nOut]``,
+BN ``weight, bias, running_mean, running_var``), same intermediate object attributes
+(``.features``, ``.metadata``, ``.spatial_size``, ``get_spatial_locations()``).
+
+PyTorch is used for device memory, autograd bookkeeping and the stream; every sparse op runs in
+the engine.  There is no CPU fallback.
+"""
+import ctypes
+import math
+
+import torch
+from torch import nn
+
+from . import _lib
+from ._lib import check, i32x3, lib
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _triple(v):
+    if isinstance(v, torch.Tensor):
+        v = v.tolist()
+    if isinstance(v, int):
+        return [v, v, v]
+    v = [int(x) for x in v]
+    if len(v) != 3:
+        raise ValueError("expected 3 spatial dimensions, got %r" % (v,))
+    return v
+
+
+def _f32c(t):
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _require_cuda(t, what):
+    if not t.is_cuda:
+        raise RuntimeError("sparseeventid_amd.%s: tensors must live on the MI355X (cuda) device; "
+                           "this engine has no CPU path" % what)
+
+
+class Metadata:
+    """scn.Metadata: owns the device hash maps and rulebooks of one batch (all levels)."""
+
+    def __init__(self):
+        h = ctypes.c_void_p()
+        check(lib().sei_metadata_create(ctypes.byref(h)))
+        self._h = h
+        self._rulebooks = {}
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and _lib._lib is not None:
+            _lib._lib.sei_metadata_destroy(h)
+            self._h = None
+
+    @property
+    def handle(self):
+        return self._h
+
+    def rows(self, spatial):
+        n = ctypes.c_int64()
+        check(lib().sei_level_rows(self._h, i32x3(spatial), ctypes.byref(n)))
+        return n.value
+
+    def batch_size(self):
+        b = ctypes.c_int32()
+        check(lib().sei_batch_size(self._h, ctypes.byref(b)))
+        return b.value
+
+    def coords(self, spatial, device):
+        n = self.rows(spatial)
+        out = torch.empty((n, 4), dtype=torch.int32, device=device)
+        check(lib().sei_level_coords(self._h, i32x3(spatial), _ptr(out), _stream()))
+        return out
+
+    def subm_rulebook(self, spatial, filter_size):
+        key = ("s", tuple(spatial), tuple(filter_size))
+        rb = self._rulebooks.get(key)
+        if rb is None:
+            h = ctypes.c_void_p()
+            check(lib().sei_subm_rulebook(self._h, i32x3(spatial), i32x3(filter_size), _stream(), ctypes.byref(h)))
+            rb = Rulebook(self, h, list(spatial))
+            self._rulebooks[key] = rb
+        return rb
+
+    def conv_rulebook(self, spatial, size, stride):
+        key = ("c", tuple(spatial), tuple(size), tuple(stride))
+        rb = self._rulebooks.get(key)
+        if rb is None:
+            h = ctypes.c_void_p()
+            out_sp = (ctypes.c_int32 * 3)()
+            check(lib().sei_conv_rulebook(self._h, i32x3(spatial), i32x3(size), i32x3(stride), _stream(),
+                                          ctypes.byref(h), out_sp))
+            rb = Rulebook(self, h, [int(x) for x in out_sp])
+            self._rulebooks[key] = rb
+        return rb
+
+
+class Rulebook:
+    """Borrowed handle of one rulebook; keeps its Metadata alive (autograd ctx holds this)."""
+
+    def __init__(self, metadata, handle, spatial_out):
+        self.metadata = metadata
+        self.h = handle
+        self.spatial_out = spatial_out
+        info = (ctypes.c_int64 * 6)()
+        check(lib().sei_rulebook_info(handle, info))
+        self.n_dst, self.n_src, self.K, self.n_rules, self.n_chunks, self.n_tiles = [int(x) for x in info]
+
+    def export(self, device):
+        start = (ctypes.c_int64 * (self.K + 1))()
+        rin = torch.empty(max(self.n_rules, 1), dtype=torch.int32, device=device)
+        rout = torch.empty(max(self.n_rules, 1), dtype=torch.int32, device=device)
+        check(lib().sei_rulebook_export(self.h, start, _ptr(rin), _ptr(rout), _stream()))
+        return list(start), rin[:self.n_rules], rout[:self.n_rules]
+
+
+class SparseConvNetTensor:
+    """scn.SparseConvNetTensor: features [N,C] fp32 + metadata + spatial_size."""
+
+    def __init__(self, features=None, metadata=None, spatial_size=None):
+        self.features = features
+        self.metadata = metadata
+        self.spatial_size = spatial_size
+
+    def get_spatial_locations(self, spatial_size=None):
+        sp = _triple(self.spatial_size if spatial_size is None else spatial_size)
+        return self.metadata.coords(sp, self.features.device).long().cpu()
+
+    def batch_size(self):
+        return self.metadata.batch_size()
+
+    def cuda(self):
+        self.features = self.features.cuda()
+        return self
+
+    def type(self, t=None):
+        if t is not None:
+            self.features = self.features.type(t)
+            return self
+        return self.features.type()
+
+    def __repr__(self):
+        return "SparseConvNetTensor<<features=%r, spatial_size=%r>>" % (
+            tuple(self.features.shape), _triple(self.spatial_size))
+
+
+# ============================================================================= autograd functions
+class _InputFeatures(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, features, metadata, n_rows):
+        ctx.md = metadata
+        ctx.n_in = features.shape[0]
+        C = features.shape[1]
+        out = torch.empty((n_rows, C), dtype=torch.float32, device=features.device)
+        check(lib().sei_input_features_fwd(metadata.handle, _ptr(features), C, _ptr(out), _stream()))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = _f32c(dout)
+        C = dout.shape[1]
+        din = torch.empty((ctx.n_in, C), dtype=torch.float32, device=dout.device)
+        check(lib().sei_input_features_bwd(ctx.md.handle, _ptr(dout), C, _ptr(din), _stream()))
+        return din, None, None
+
+
+class _Conv(torch.autograd.Function):
+    """Shared by SubmanifoldConvolution and Convolution: the rulebook decides which."""
+
+    @staticmethod
+    def forward(ctx, features, weight, bias, rb):
+        nIn, nOut = weight.shape[1], weight.shape[2]
+        if features.shape[1] != nIn:
+            raise RuntimeError("convolution: input has %d planes, weight expects %d" % (features.shape[1], nIn))
+        if features.shape[0] != rb.n_src:
+            raise RuntimeError("convolution: %d feature rows but the metadata level has %d"
+                               % (features.shape[0], rb.n_src))
+        ctx.rb = rb
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(features, weight)
+        out = torch.empty((rb.n_dst, nOut), dtype=torch.float32, device=features.device)
+        check(lib().sei_conv_forward(rb.h, _ptr(features), _ptr(weight), _ptr(bias), _ptr(out), nIn, nOut, _stream()))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        features, weight = ctx.saved_tensors
+        rb = ctx.rb
+        dout = _f32c(dout)
+        nIn, nOut = weight.shape[1], weight.shape[2]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((rb.n_src, nIn), dtype=torch.float32, device=dout.device)
+            check(lib().sei_conv_backward_input(rb.h, _ptr(dout), _ptr(weight), _ptr(dx), nIn, nOut, _stream()))
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw = torch.empty_like(weight)
+            if ctx.has_bias:
+                db = torch.empty((nOut,), dtype=torch.float32, device=dout.device)
+            check(lib().sei_conv_backward_weight(rb.h, _ptr(features), _ptr(dout), _ptr(dw), _ptr(db), nIn, nOut,
+                                                 _stream()))
+        return dx, dw, db, None
+
+
+class _BatchNorm(torch.autograd.Function):
+    """BN (+ optional residual add) + leaky activation in two passes over the rows."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, training, leak, residual):
+        n, C = x.shape
+        y = torch.empty_like(x)
+        save_mean = torch.empty((C,), dtype=torch.float32, device=x.device)
+        save_invstd = torch.empty((C,), dtype=torch.float32, device=x.device)
+        check(lib().sei_bn_forward(_ptr(x), n, C, _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
+                                   eps, momentum, 1 if training else 0, leak, _ptr(residual), _ptr(y),
+                                   _ptr(save_mean), _ptr(save_invstd), _stream()))
+        ctx.leak = leak
+        ctx.training = training
+        ctx.has_res = residual is not None
+        ctx.has_affine = gamma is not None
+        ctx.save_for_backward(x, y, gamma, save_mean, save_invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, gamma, save_mean, save_invstd = ctx.saved_tensors
+        dy = _f32c(dy)
+        n, C = x.shape
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if ctx.has_res else None
+        dgamma = torch.empty((C,), dtype=torch.float32, device=x.device) if ctx.has_affine else None
+        dbeta = torch.empty((C,), dtype=torch.float32, device=x.device) if ctx.has_affine else None
+        check(lib().sei_bn_backward(_ptr(x), _ptr(y), _ptr(dy), n, C, _ptr(gamma), _ptr(save_mean), _ptr(save_invstd),
+                                    ctx.leak, 1 if ctx.training else 0, _ptr(dx), _ptr(dres), _ptr(dgamma),
+                                    _ptr(dbeta), _stream()))
+        return dx, dgamma, dbeta, None, None, None, None, None, None, dres
+
+
+class _Leaky(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, leak):
+        y = torch.empty_like(x)
+        check(lib().sei_leaky_forward(_ptr(x), _ptr(y), x.numel(), leak, _stream()))
+        ctx.leak = leak
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = _f32c(dy)
+        dx = torch.empty_like(y)
+        check(lib().sei_leaky_backward(_ptr(y), _ptr(dy), _ptr(dx), y.numel(), ctx.leak, _stream()))
+        return dx, None
+
+
+class _Add(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        out = torch.empty_like(a)
+        check(lib().sei_add_forward(_ptr(a), _ptr(b), _ptr(out), a.numel(), _stream()))
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        return d, d
+
+
+class _AddLeaky(torch.autograd.Function):
+    """leaky(a + b): AddTable + LeakyReLU of the residual block in one pass."""
+
+    @staticmethod
+    def forward(ctx, a, b, leak):
+        y = torch.empty_like(a)
+        check(lib().sei_add_leaky_forward(_ptr(a), _ptr(b), _ptr(y), a.numel(), leak, _stream()))
+        ctx.leak = leak
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = _f32c(dy)
+        dz = torch.empty_like(y)
+        check(lib().sei_leaky_backward(_ptr(y), _ptr(dy), _ptr(dz), y.numel(), ctx.leak, _stream()))
+        return dz, dz, None
+
+
+class _SparseToDense(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, features, metadata, spatial, n_planes):
+        B = metadata.batch_size()
+        ctx.md, ctx.spatial = metadata, spatial
+        ctx.n = features.shape[0]
+        dense = torch.empty((B, n_planes, spatial[0], spatial[1], spatial[2]), dtype=torch.float32,
+                            device=features.device)
+        check(lib().sei_sparse_to_dense_forward(metadata.handle, i32x3(spatial), _ptr(features), n_planes, _ptr(dense),
+                                                _stream()))
+        return dense
+
+    @staticmethod
+    def backward(ctx, ddense):
+        ddense = _f32c(ddense)
+        C = ddense.shape[1]
+        dfeat = torch.empty((ctx.n, C), dtype=torch.float32, device=ddense.device)
+        check(lib().sei_sparse_to_dense_backward(ctx.md.handle, i32x3(ctx.spatial), _ptr(ddense), C, _ptr(dfeat),
+                                                 _stream()))
+        return dfeat, None, None, None
+
+
+# ============================================================================= functional helpers
+def batchnorm_act(x, bn, leak=1.0, residual=None):
+    """Fused BatchNormalization (+AddTable residual) + LeakyReLU on a features tensor."""
+    return _BatchNorm.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum,
+                            bn.training, float(leak), residual)
+
+
+# ============================================================================= modules
+class InputLayer(nn.Module):
+    """scn.InputLayer(dimension, spatial_size, mode=3)  (resnet.py:26-29,40-43).
+
+    forward((coords [N,4] (x0,x1,x2,batch) any real dtype / device, features [N,C], batch_size)).
+    mode: 0/2 keep first duplicate, 1 keep last, 3 sum, 4 mean.
+    """
+
+    def __init__(self, dimension, spatial_size, mode=3):
+        super().__init__()
+        if dimension != 3:
+            raise ValueError("sparseeventid_amd supports dimension=3 (2-D data uses [planes,H,W], resnet.py:26-29)")
+        self.dimension = dimension
+        self.spatial_size = torch.LongTensor(_triple(spatial_size))
+        self.mode = mode
+        self.device = None
+
+    def forward(self, input):
+        coords, features = input[0], input[1]
+        batch_size = int(input[2]) if len(input) > 2 and input[2] is not None else None
+        dev = features.device if isinstance(features, torch.Tensor) and features.is_cuda else torch.device("cuda")
+        if not torch.cuda.is_available():
+            raise RuntimeError("sparseeventid_amd.InputLayer: no MI355X (cuda) device; this engine has no CPU path")
+        coords = torch.as_tensor(coords)
+        features = torch.as_tensor(features)
+        if coords.dim() != 2 or coords.shape[1] != 4:
+            raise ValueError("InputLayer: coords must be [N,4] = (x0,x1,x2,batch)")
+        # upstream: coords.cpu().long(); here the cast happens on the device (plumbing)
+        c32 = coords.to(device=dev).to(torch.int32).contiguous()
+        feats = _f32c(features.to(device=dev))
+        if feats.dim() == 1:
+            feats = feats[:, None]
+        if batch_size is None:
+            batch_size = int(c32[:, 3].max().item()) + 1 if c32.shape[0] else 1
+        md = Metadata()
+        sp = _triple(self.spatial_size)
+        n_rows = ctypes.c_int64()
+        check(lib().sei_input_build(md.handle, _ptr(c32), c32.shape[0], i32x3(sp), batch_size, self.mode, _stream(),
+                                    ctypes.byref(n_rows)))
+        out = SparseConvNetTensor(metadata=md, spatial_size=self.spatial_size)
+        out.features = _InputFeatures.apply(feats, md, n_rows.value)
+        return out
+
+    def __repr__(self):
+        return "InputLayer(spatial_size=%r, mode=%d)" % (_triple(self.spatial_size), self.mode)
+
+
+class SubmanifoldConvolution(nn.Module):
+    """scn.SubmanifoldConvolution(dimension, nIn, nOut, filter_size, bias) (resnet.py:30-36,44-50,105-110)."""
+
+    def __init__(self, dimension, nIn, nOut, filter_size, bias, groups=1):
+        super().__init__()
+        if dimension != 3 or groups != 1:
+            raise ValueError("only dimension=3, groups=1 is supported")
+        self.dimension, self.nIn, self.nOut = dimension, nIn, nOut
+        self.filter_size = _triple(filter_size)
+        self.filter_volume = self.filter_size[0] * self.filter_size[1] * self.filter_size[2]
+        std = (2.0 / nIn / self.filter_volume) ** 0.5
+        self.weight = nn.Parameter(torch.empty(self.filter_volume, nIn, nOut).normal_(0, std))
+        if bias:
+            self.bias = nn.Parameter(torch.zeros(nOut))
+        else:
+            self.register_parameter("bias", None)
+
+    def forward(self, input):
+        _require_cuda(input.features, "SubmanifoldConvolution")
+        sp = _triple(input.spatial_size)
+        rb = input.metadata.subm_rulebook(sp, self.filter_size)
+        out = SparseConvNetTensor(metadata=input.metadata, spatial_size=input.spatial_size)
+        out.features = _Conv.apply(_f32c(input.features), self.weight, self.bias, rb)
+        return out
+
+    def input_spatial_size(self, out_size):
+        return out_size
+
+    def __repr__(self):
+        return "SubmanifoldConvolution %d->%d C%s" % (self.nIn, self.nOut, "x".join(map(str, self.filter_size)))
+
+
+ValidConvolution = SubmanifoldConvolution
+
+
+class Convolution(nn.Module):
+    """scn.Convolution(dimension, nIn, nOut, filter_size, filter_stride, bias) (sparse_building_blocks.py:110-117)."""
+
+    def __init__(self, dimension, nIn, nOut, filter_size, filter_stride, bias, groups=1):
+        super().__init__()
+        if dimension != 3 or groups != 1:
+            raise ValueError("only dimension=3, groups=1 is supported")
+        self.dimension, self.nIn, self.nOut = dimension, nIn, nOut
+        self.filter_size = _triple(filter_size)
+        self.filter_stride = _triple(filter_stride)
+        self.filter_volume = self.filter_size[0] * self.filter_size[1] * self.filter_size[2]
+        std = (2.0 / nIn / self.filter_volume) ** 0.5
+        self.weight = nn.Parameter(torch.empty(self.filter_volume, nIn, nOut).normal_(0, std))
+        if bias:
+            self.bias = nn.Parameter(torch.zeros(nOut))
+        else:
+            self.register_parameter("bias", None)
+
+    def forward(self, input):
+        _require_cuda(input.features, "Convolution")
+        sp = _triple(input.spatial_size)
+        rb = input.metadata.conv_rulebook(sp, self.filter_size, self.filter_stride)
+        out = SparseConvNetTensor(metadata=input.metadata, spatial_size=torch.LongTensor(rb.spatial_out))
+        out.features = _Conv.apply(_f32c(input.features), self.weight, self.bias, rb)
+        return out
+
+    def input_spatial_size(self, out_size):
+        o = _triple(out_size)
+        return torch.LongTensor([(o[d] - 1) * self.filter_stride[d] + self.filter_size[d] for d in range(3)])
+
+    def __repr__(self):
+        return "Convolution %d->%d C%s/%s" % (self.nIn, self.nOut, "x".join(map(str, self.filter_size)),
+                                              "x".join(map(str, self.filter_stride)))
+
+
+class BatchNormalization(nn.Module):
+    """scn.BatchNormalization(nPlanes, eps=1e-4, momentum=0.9, affine=True, leakiness=1)
+    (sparse_building_blocks.py:39,122): statistics over all active rows of the batch."""
+
+    def __init__(self, nPlanes, eps=1e-4, momentum=0.9, affine=True, leakiness=1):
+        super().__init__()
+        self.nPlanes, self.eps, self.momentum, self.affine, self.leakiness = nPlanes, eps, momentum, affine, leakiness
+        self.register_buffer("running_mean", torch.zeros(nPlanes))
+        self.register_buffer("running_var", torch.ones(nPlanes))
+        if affine:
+            self.weight = nn.Parameter(torch.ones(nPlanes))
+            self.bias = nn.Parameter(torch.zeros(nPlanes))
+        else:
+            self.register_parameter("weight", None)
+            self.register_parameter("bias", None)
+
+    def forward_features(self, x, leak=None, residual=None):
+        if x.shape[1] != self.nPlanes:
+            raise RuntimeError("BatchNormalization: %d planes, expected %d" % (x.shape[1], self.nPlanes))
+        return batchnorm_act(_f32c(x), self, self.leakiness if leak is None else leak, residual)
+
+    def forward(self, input):
+        _require_cuda(input.features, "BatchNormalization")
+        out = SparseConvNetTensor(metadata=input.metadata, spatial_size=input.spatial_size)
+        out.features = self.forward_features(input.features)
+        return out
+
+    def input_spatial_size(self, out_size):
+        return out_size
+
+    def __repr__(self):
+        return "BatchNorm(%d,eps=%g,momentum=%g,affine=%s,leakiness=%g)" % (
+            self.nPlanes, self.eps, self.momentum, self.affine, self.leakiness)
+
+
+class BatchNormReLU(BatchNormalization):
+    def __init__(self, nPlanes, eps=1e-4, momentum=0.9):
+        super().__init__(nPlanes, eps, momentum, True, 0)
+
+
+class BatchNormLeakyReLU(BatchNormalization):
+    def __init__(self, nPlanes, eps=1e-4, momentum=0.9, leakiness=0.333):
+        super().__init__(nPlanes, eps, momentum, True, leakiness)
+
+
+class LeakyReLU(nn.Module):
+    """scn.LeakyReLU(leak=1/3) (sparse_building_blocks.py:20,80,128)."""
+
+    def __init__(self, leak=1 / 3):
+        super().__init__()
+        self.leak = leak
+
+    def forward(self, input):
+        _require_cuda(input.features, "LeakyReLU")
+        out = SparseConvNetTensor(metadata=input.metadata, spatial_size=input.spatial_size)
+        out.features = _Leaky.apply(_f32c(input.features), float(self.leak))
+        return out
+
+    def input_spatial_size(self, out_size):
+        return out_size
+
+
+class ReLU(LeakyReLU):
+    def __init__(self):
+        super().__init__(0.0)
+
+
+class Identity(nn.Module):
+    """scn.Identity (sparse_building_blocks.py:76,79)."""
+
+    def forward(self, input):
+        return input
+
+    def input_spatial_size(self, out_size):
+        return out_size
+
+
+class AddTable(nn.Module):
+    """scn.AddTable (sparse_building_blocks.py:82,96): sum of row-aligned feature tensors."""
+
+    def forward(self, input):
+        _require_cuda(input[0].features, "AddTable")
+        out = SparseConvNetTensor(metadata=input[0].metadata, spatial_size=input[0].spatial_size)
+        f = _f32c(input[0].features)
+        for other in input[1:]:
+            if other.features.shape != f.shape:
+                raise RuntimeError("AddTable: feature shapes differ")
+            f = _Add.apply(f, _f32c(other.features))
+        out.features = f
+        return out
+
+    def input_spatial_size(self, out_size):
+        return out_size
+
+
+class SparseToDense(nn.Module):
+    """scn.SparseToDense(dimension, nPlanes) (resnet.py:124-125): -> [B, nPlanes, D0, D1, D2]."""
+
+    def __init__(self, dimension, nPlanes):
+        super().__init__()
+        self.dimension, self.nPlanes = dimension, nPlanes
+
+    def forward(self, input):
+        _require_cuda(input.features, "SparseToDense")
+        if input.features.shape[1] != self.nPlanes:
+            raise RuntimeError("SparseToDense: %d planes, expected %d" % (input.features.shape[1], self.nPlanes))
+        return _SparseToDense.apply(_f32c(input.features), input.metadata, _triple(input.spatial_size), self.nPlanes)
+
+    def input_spatial_size(self, out_size):
+        return out_size
+
+
+class Sequential(nn.Sequential):
+    def input_spatial_size(self, out_size):
+        for m in reversed(self._modules.values()):
+            out_size = m.input_spatial_size(out_size)
+        return out_size
+
+    def add(self, module):
+        self._modules[str(len(self._modules))] = module
+        return self

@@ -1,0 +1,232 @@
+"""GPU parity tests: every engine op (through the scn module surface -> C ABI -> HIP kernels)
+against the CPU oracle (oracle/scn_cpu.py) on the same seeded inputs.
+Tolerance: 1e-4 relative fp32 (BASELINE.json north_star); integer work is compared exactly.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import scn_cpu
+from tests.util import blob_cloud, random_cloud, rel_err, sort_rows
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _engine():
+    import sparseeventid_amd.scn as scn
+    return scn
+
+
+def _input(scn, coords, feats, B, sp, mode=3, requires_grad=False):
+    f = torch.from_numpy(feats).cuda().requires_grad_(requires_grad)
+    t = scn.InputLayer(3, sp, mode=mode)((torch.from_numpy(coords), f, B))
+    return t, f
+
+
+def test_library_loaded_is_in_tree():
+    from sparseeventid_amd import _lib
+    assert _lib.lib().sei_abi_version() == 1
+    assert _lib.LIB_PATH.endswith("sparseeventid_amd/libsparseeventid_amd.so")
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])
+def test_input_layer_rows_and_features(mode):
+    scn = _engine()
+    sp, B = [20, 24, 18], 3
+    coords, feats = random_cloud(11, B, sp, [300, 0, 150], 2, dup_frac=0.0 if mode == 0 else 0.3)
+    t, _ = _input(scn, coords, feats, B, sp, mode)
+    o = scn_cpu.input_layer(coords, torch.from_numpy(feats), B, sp, mode)
+    # integer part: identical rows in identical (first-appearance) order
+    assert np.array_equal(t.get_spatial_locations().numpy(), o.coords.astype(np.int64))
+    assert rel_err(t.features, o.features) < 1e-6
+
+
+def test_input_layer_empty_and_oob():
+    scn = _engine()
+    t = scn.InputLayer(3, [8, 8, 8])((torch.zeros(0, 4), torch.zeros(0, 1).cuda(), 2))
+    assert t.features.shape == (0, 1)
+    with pytest.raises(RuntimeError):
+        scn.InputLayer(3, [8, 8, 8])((torch.tensor([[1., 2., 8., 0.]]), torch.ones(1, 1).cuda(), 1))
+    with pytest.raises(RuntimeError):
+        scn.InputLayer(3, [8, 8, 8])((torch.tensor([[1., 2., 3., 1.]]), torch.ones(1, 1).cuda(), 1))
+
+
+def _rule_set(start, ri, ro, K):
+    s = set()
+    for k in range(K):
+        for a in range(int(start[k]), int(start[k + 1])):
+            s.add((k, int(ri[a]), int(ro[a])))
+    return s
+
+
+@pytest.mark.parametrize("filt", [[3, 3, 3], [5, 5, 5], [1, 3, 3], [1, 1, 1]])
+def test_subm_rulebook_exact(filt):
+    scn = _engine()
+    sp, B = [16, 12, 20], 2
+    coords, feats = blob_cloud(5, B, sp, 300, 1)
+    t, _ = _input(scn, coords, feats, B, sp)
+    rb = t.metadata.subm_rulebook(sp, filt)
+    start, ri, ro = rb.export("cuda")
+    o = scn_cpu.input_layer(coords, torch.from_numpy(feats), B, sp)
+    ostart, ori, oro = scn_cpu.subm_rules(o.coords, sp, filt)
+    K = filt[0] * filt[1] * filt[2]
+    assert rb.n_rules == len(ori)
+    assert list(start) == [int(x) for x in ostart]
+    assert _rule_set(start, ri.cpu().numpy(), ro.cpu().numpy(), K) == _rule_set(ostart, ori, oro, K)
+
+
+@pytest.mark.parametrize("sp,size,stride", [([16, 12, 20], [2, 2, 2], [2, 2, 2]), ([15, 13, 9], [2, 2, 2], [2, 2, 2]),
+                                            ([3, 16, 12], [1, 2, 2], [1, 2, 2]), ([12, 12, 12], [3, 3, 3], [2, 2, 2])])
+def test_strided_rulebook_exact(sp, size, stride):
+    scn = _engine()
+    B = 2
+    coords, feats = random_cloud(6, B, sp, 250, 1)
+    t, _ = _input(scn, coords, feats, B, sp)
+    rb = t.metadata.conv_rulebook(sp, size, stride)
+    o = scn_cpu.input_layer(coords, torch.from_numpy(feats), B, sp)
+    oc, osp, ostart, ori, oro = scn_cpu.conv_rules(o.coords, sp, size, stride)
+    assert rb.spatial_out == osp
+    got = t.metadata.coords(osp, "cuda").cpu().numpy()
+    assert np.array_equal(got, oc)          # same sites, same (first-appearance) order
+    start, ri, ro = rb.export("cuda")
+    K = size[0] * size[1] * size[2]
+    assert _rule_set(start, ri.cpu().numpy(), ro.cpu().numpy(), K) == _rule_set(ostart, ori, oro, K)
+
+
+CONV_CASES = [(1, 32, [5, 5, 5]), (32, 32, [3, 3, 3]), (64, 64, [3, 3, 3]), (96, 96, [3, 3, 3]),
+              (128, 128, [3, 3, 3]), (160, 160, [3, 3, 3]), (192, 192, [3, 3, 3]), (192, 128, [1, 1, 1]),
+              (16, 48, [1, 3, 3]), (3, 5, [3, 3, 3]), (32, 80, [3, 3, 3])]
+
+
+@pytest.mark.parametrize("ci,co,filt", CONV_CASES)
+def test_subm_conv_forward_backward(ci, co, filt):
+    scn = _engine()
+    sp, B = [14, 12, 16], 2
+    coords, feats = blob_cloud(21, B, sp, 260, ci)
+    t, f = _input(scn, coords, feats, B, sp, requires_grad=True)
+    conv = scn.SubmanifoldConvolution(3, ci, co, filt, True).cuda()
+    with torch.no_grad():
+        conv.bias.normal_()
+    out = conv(t)
+    g = torch.randn(out.features.shape, generator=torch.Generator().manual_seed(3))
+    out.features.backward(g.cuda())
+
+    fo = torch.from_numpy(feats).requires_grad_(True)
+    W = conv.weight.detach().cpu().requires_grad_(True)
+    b = conv.bias.detach().cpu().requires_grad_(True)
+    o = scn_cpu.input_layer(coords, fo, B, sp)
+    oo = scn_cpu.subm_conv(o, W, b, filt)
+    oo.features.backward(g)
+    assert rel_err(out.features, oo.features) < TOL
+    assert rel_err(conv.weight.grad, W.grad) < TOL
+    assert rel_err(conv.bias.grad, b.grad) < TOL
+    assert rel_err(f.grad, fo.grad) < TOL
+
+
+@pytest.mark.parametrize("ci,co,size", [(32, 64, [2, 2, 2]), (64, 96, [2, 2, 2]), (160, 192, [2, 2, 2]),
+                                        (16, 32, [1, 2, 2]), (5, 7, [2, 2, 2]), (32, 32, [3, 3, 3])])
+def test_strided_conv_forward_backward(ci, co, size):
+    scn = _engine()
+    sp, B = [15, 12, 18], 2
+    if size[0] == 1:
+        sp = [3, 14, 18]
+    stride = [2 if s > 1 else 1 for s in size]
+    coords, feats = blob_cloud(22, B, sp, 240, ci)
+    t, f = _input(scn, coords, feats, B, sp, requires_grad=True)
+    conv = scn.Convolution(3, ci, co, size, stride, False).cuda()
+    out = conv(t)
+    fo = torch.from_numpy(feats).requires_grad_(True)
+    W = conv.weight.detach().cpu().requires_grad_(True)
+    o = scn_cpu.input_layer(coords, fo, B, sp)
+    oo = scn_cpu.strided_conv(o, W, None, size, stride)
+    assert np.array_equal(out.get_spatial_locations().numpy(), oo.coords.astype(np.int64))
+    g = torch.randn(oo.features.shape, generator=torch.Generator().manual_seed(4))
+    out.features.backward(g.cuda())
+    oo.features.backward(g)
+    assert rel_err(out.features, oo.features) < TOL
+    assert rel_err(conv.weight.grad, W.grad) < TOL
+    assert rel_err(f.grad, fo.grad) < TOL
+
+
+@pytest.mark.parametrize("C,leak,with_res", [(32, 1.0, False), (32, 1 / 3, False), (96, 1 / 3, True), (7, 0.0, False),
+                                             (192, 1 / 3, True), (1, 1 / 3, False)])
+def test_batchnorm_fused_forward_backward(C, leak, with_res):
+    scn = _engine()
+    n = 3001
+    gen = torch.Generator().manual_seed(9)
+    x = (torch.randn(n, C, generator=gen) * 2.5 + 0.7)
+    r = torch.randn(n, C, generator=gen) if with_res else None
+    g = torch.randn(n, C, generator=gen)
+    bn = scn.BatchNormalization(C).cuda()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_()
+    xg = x.clone().cuda().requires_grad_(True)
+    rg = r.clone().cuda().requires_grad_(True) if with_res else None
+    y = bn.forward_features(xg, leak=leak, residual=rg)
+    y.backward(g.cuda())
+
+    xo = x.clone().requires_grad_(True)
+    ro = r.clone().requires_grad_(True) if with_res else None
+    w = bn.weight.detach().cpu().requires_grad_(True)
+    b = bn.bias.detach().cpu().requires_grad_(True)
+    rm, rv = torch.zeros(C), torch.ones(C)
+    t = scn_cpu.OracleTensor(xo, np.zeros((n, 4), np.int32), [1, 1, 1], 1)
+    z = scn_cpu.batchnorm(t, w, b, rm, rv).features
+    if with_res:
+        z = z + ro
+    yo = torch.where(z > 0, z, z * leak)
+    yo.backward(g)
+    assert rel_err(y, yo) < TOL
+    assert rel_err(xg.grad, xo.grad) < TOL
+    assert rel_err(bn.weight.grad, w.grad) < TOL
+    assert rel_err(bn.bias.grad, b.grad) < TOL
+    if with_res:
+        assert rel_err(rg.grad, ro.grad) < TOL
+    assert rel_err(bn.running_mean, rm) < 1e-5 and rel_err(bn.running_var, rv) < 1e-5
+    # eval mode uses the running statistics
+    bn.eval()
+    ye = bn.forward_features(x.cuda(), leak=1.0)
+    ze = scn_cpu.batchnorm(scn_cpu.OracleTensor(x, None, [1, 1, 1], 1), w.detach(), b.detach(), rm, rv,
+                           training=False).features
+    assert rel_err(ye, ze) < TOL
+
+
+def test_elementwise_and_dense():
+    scn = _engine()
+    sp, B, C = [6, 5, 7], 3, 8
+    coords, feats = random_cloud(31, B, sp, 60, C)
+    t, f = _input(scn, coords, feats, B, sp, requires_grad=True)
+    a = scn.LeakyReLU()(t)
+    s = scn.AddTable()([a, t])
+    r = scn.ReLU()(s)
+    d = scn.SparseToDense(3, C)(r)
+    assert d.shape == (B, C, 6, 5, 7)
+    g = torch.randn(d.shape, generator=torch.Generator().manual_seed(1))
+    d.backward(g.cuda())
+    fo = torch.from_numpy(feats).requires_grad_(True)
+    o = scn_cpu.input_layer(coords, fo, B, sp)
+    oa = scn_cpu.leaky_relu(o)
+    os_ = scn_cpu.add_table([oa, o])
+    orr = scn_cpu.leaky_relu(os_, 0.0)
+    od = scn_cpu.sparse_to_dense(orr, C)
+    od.backward(g)
+    assert rel_err(d, od) < 1e-6
+    assert rel_err(f.grad, fo.grad) < 1e-6
+
+
+def test_conv_is_deterministic():
+    scn = _engine()
+    sp, B = [14, 12, 16], 2
+    coords, feats = blob_cloud(40, B, sp, 300, 32)
+    conv = scn.SubmanifoldConvolution(3, 32, 32, 3, True).cuda()
+    outs = []
+    for _ in range(2):
+        t, f = _input(scn, coords, feats, B, sp, requires_grad=True)
+        o = conv(t)
+        o.features.sum().backward()
+        outs.append((o.features.detach().clone(), conv.weight.grad.clone(), f.grad.clone()))
+        conv.weight.grad = None
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
