@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py -- the reference's headline metric on MI355X (BASELINE.json):
+events/sec (fwd+bwd) of the DUNE-3D sparse ResNet, 64-event batch per GPU, synthetic ~50k-voxel
+events in a 900^3 grid.  One "step" = forward + focal loss + backward + gradient
+all-reduce (N>1) + Adam step over one batch whose input tensors are already resident in HBM.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line (contract in the build prompt) carrying `roofline` (dominant kernel =
+the MFMA gather-GEMM conv forward/dX kernel, HIP-event timed inside the timed region) and, at N=1,
+`cpu_baseline` (the CPU oracle -- a port of the SparseConvNet-CPU algorithm -- on a bounded sample).
+"""
+import argparse
+import json
+import multiprocessing as mp
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+
+def _gen_event(args):
+    from sparseeventid_amd.data import synthetic_event, uniform_event
+    seed, grid, nvox, kind = args
+    return (synthetic_event if kind == "tracks" else uniform_event)(seed, grid, nvox)
+
+
+def generate_batch(rank, batch_index, batch, grid, nvox, kind, workers):
+    """larcv-layout [B,1,nvox,4] fp32 + labels; seed = 1000003*rank + 64*batch + event."""
+    jobs = [(1000003 * rank + 64 * batch_index + e, grid, nvox, kind) for e in range(batch)]
+    if workers > 1:
+        with mp.get_context("fork").Pool(workers) as pool:
+            evs = pool.map(_gen_event, jobs)
+    else:
+        evs = [_gen_event(j) for j in jobs]
+    arr = np.stack(evs)[:, None]
+    rng = np.random.default_rng(7 + 1000003 * rank + batch_index)
+    names = ("labelneutID", "labelprotID", "labelnpiID", "labelcpiID")
+    labels = {k: rng.integers(0, n, batch).astype(np.int64) for k, n in zip(names, (3, 3, 2, 2))}
+    return arr, labels
+
+
+def cpu_baseline(arr, labels, image_size, n_events, fwd_only):
+    """Time the CPU oracle (port of the SCN-CPU algorithm; the SCN binary is unavailable) on the first
+    `n_events` events of the same batch: forward+backward (or forward only).  Checker code, timed
+    here ONLY as the reported baseline."""
+    import torch
+    from oracle import scn_cpu
+    from sparseeventid_amd.data import larcvsparse_to_scnsparse_3d
+    heads = {"labelneutID": 3, "labelprotID": 3, "labelnpiID": 2, "labelcpiID": 2}
+    cfg = scn_cpu.NetConfig()
+    sd = scn_cpu.init_params(cfg, seed=0, heads=heads)
+    sd = {k: (v.requires_grad_(True) if "running" not in k else v) for k, v in sd.items()}
+    c, f, b = larcvsparse_to_scnsparse_3d(arr[:n_events])
+    lab = {k: torch.from_numpy(v[:n_events]) for k, v in labels.items()}
+    t0 = time.time()
+    if fwd_only:
+        with torch.no_grad():
+            dense = scn_cpu.encoder_forward(sd, cfg, (c, torch.from_numpy(f), b), image_size)
+            scn_cpu.head_forward(sd, dense, heads)
+    else:
+        dense = scn_cpu.encoder_forward(sd, cfg, (c, torch.from_numpy(f), b), image_size)
+        loss = scn_cpu.focal_loss(scn_cpu.head_forward(sd, dense, heads), lab)
+        loss.backward()
+    dt = time.time() - t0
+    return {"value": n_events / dt, "unit": "events/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d of the batch's events, %s, one pass (%.1f s); CPU restatement of the SparseConvNet-CPU "
+                      "algorithm (SCN binary unavailable)" % (n_events, "fwd" if fwd_only else "fwd+bwd", dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64, help="events per GPU")
+    ap.add_argument("--voxels", type=int, default=50000)
+    ap.add_argument("--grid", type=int, nargs=3, default=[900, 900, 900])
+    ap.add_argument("--kind", default="tracks", choices=["tracks", "uniform"])
+    ap.add_argument("--mode", default="train", choices=["train", "fwd"])
+    ap.add_argument("--cpu-events", type=int, default=4, help="events in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-prof", action="store_true", help="skip HIP-event timing of the conv kernels")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
+    # synthetic input is generated BEFORE the GPU is touched (fork pool)
+    ncpu = os.cpu_count() or 8
+    workers = max(1, min(16, ncpu // max(world, 1)))
+    grid = tuple(args.grid)
+    arr, labels = generate_batch(rank, 0, args.batch, grid, args.voxels, args.kind, workers)
+
+    import torch
+    import torch.distributed as dist
+    from sparseeventid_amd import _lib
+    from sparseeventid_amd.distributed import init_from_env
+    from sparseeventid_amd.train import Trainer
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
+    torch.cuda.set_device(local)
+    init_from_env("nccl" if world > 1 else None)
+    image_size = [1] + list(grid)
+    tr = Trainer(image_size=image_size, device="cuda", seed=0)
+    tr.arena.broadcast_parameters()
+    image, lab = tr.stage(tr.to_scn_input(arr), labels)   # inputs resident in HBM before timing
+
+    def step():
+        if args.mode == "train":
+            tr.train_step(image, lab)
+        else:
+            with torch.no_grad():
+                tr.forward(image)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    lib = _lib.lib()
+    fence()
+    if not args.no_prof:
+        lib.sei_prof_reset()
+        lib.sei_prof_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    lib.sei_prof_enable(0)
+    ms = dt / args.steps * 1e3
+    if world > 1:
+        t = torch.tensor([ms], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ms = float(t.item())
+
+    if rank == 0:
+        import ctypes
+        roof = None
+        if not args.no_prof:
+            # dominant kernel: the gather->MFMA->LDS-accumulate conv kernel (forward launches + dX launches run the
+            # same kernel); algorithmic flops = 2*R*Cin*Cout per launch, duration from HIP events.
+            q = (ctypes.c_double * 4)()
+            tot_ms = tot_fl = tot_n = 0.0
+            kinds = {}
+            for kind, name in ((0, "conv_fwd"), (1, "conv_bwd_input"), (2, "conv_bwd_weight"), (3, "rulebook_build"),
+                               (4, "batchnorm")):
+                lib.sei_prof_query(kind, q)
+                kinds[name] = {"launches": q[0], "ms": q[1], "gflop": q[2] / 1e9, "gbyte": q[3] / 1e9}
+                if kind in (0, 1):
+                    tot_n += q[0]; tot_ms += q[1]; tot_fl += q[2]
+            if tot_ms > 0:
+                ach = tot_fl / (tot_ms * 1e-3) / 1e12
+                roof = {"bound": "mfma", "kernel": "conv_tile_mfma_kernel (fwd + dX launches)", "achieved": ach,
+                        "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3, "traffic": None,
+                        "launches_per_step": tot_n / args.steps, "avg_launch_ms": tot_ms / max(tot_n, 1),
+                        "per_kind_per_step": {k: {kk: vv / args.steps for kk, vv in v.items()} for k, v in kinds.items()}}
+        cpu = None
+        if world == 1 and args.cpu_events > 0:
+            cpu = cpu_baseline(arr, labels, image_size, min(args.cpu_events, args.batch), args.mode == "fwd")
+        out = {
+            "metric": "events/sec (fwd+bwd) DUNE-3D sparse ResNet, 64-event batch, 1/2/4/8 MI355X"
+                      if args.mode == "train" else "events/sec (fwd only) DUNE-3D sparse ResNet",
+            "value": args.batch * world / (ms * 1e-3), "unit": "events/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "dune3d sparse ResNet (depth 5, 32 filters, 4 res-blocks/level) %s, "
+                                   "%d events/GPU x %d voxels in %dx%dx%d, %s generator"
+                                   % ("fwd+bwd+Adam" if args.mode == "train" else "fwd", args.batch, args.voxels,
+                                      grid[0], grid[1], grid[2], args.kind),
+                       "global_batch": args.batch * world, "parallelism": "dp%d" % world},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

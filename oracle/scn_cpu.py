@@ -152,15 +152,41 @@ def input_layer(coords, features, batch_size, spatial_size, mode=3):
     return OracleTensor(out, oc, _triple(spatial_size), batch_size)
 
 
+class _RuleConv(torch.autograd.Function):
+    """SCN-CPU inner loops [upstream, SURVEY.md 2.2]: per offset k,
+    forward  out[rules_k.out] += in[rules_k.in] @ W[k]       (index_select -> mm -> index_add_)
+    backward dIn[in] += dOut[out] @ W[k]^T ;  dW[k] += in[in]^T @ dOut[out]."""
+
+    @staticmethod
+    def forward(ctx, x, W, start, ri_t, ro_t, n_out):
+        out = torch.zeros(n_out, W.shape[2], dtype=x.dtype)
+        for k in range(W.shape[0]):
+            a, b = int(start[k]), int(start[k + 1])
+            if b > a:
+                out.index_add_(0, ro_t[a:b], x.index_select(0, ri_t[a:b]) @ W[k])
+        ctx.save_for_backward(x, W, ri_t, ro_t)
+        ctx.start = start
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, W, ri_t, ro_t = ctx.saved_tensors
+        start = ctx.start
+        dx = torch.zeros_like(x) if ctx.needs_input_grad[0] else None
+        dW = torch.zeros_like(W)
+        for k in range(W.shape[0]):
+            a, b = int(start[k]), int(start[k + 1])
+            if b > a:
+                g = dout.index_select(0, ro_t[a:b])
+                if dx is not None:
+                    dx.index_add_(0, ri_t[a:b], g @ W[k].t())
+                dW[k] = x.index_select(0, ri_t[a:b]).t() @ g
+        return dx, dW, None, None, None, None
+
+
 def _apply_rules(x, W, start, ri, ro, n_out):
-    """SCN-CPU inner loop: per offset k, gather -> mm -> scatter-add."""
-    out = torch.zeros(n_out, W.shape[2], dtype=x.dtype)
     ri_t = torch.from_numpy(ri.astype(np.int64)); ro_t = torch.from_numpy(ro.astype(np.int64))
-    for k in range(W.shape[0]):
-        a, b = int(start[k]), int(start[k + 1])
-        if b > a:
-            out = out.index_add(0, ro_t[a:b], x.index_select(0, ri_t[a:b]) @ W[k])
-    return out
+    return _RuleConv.apply(x, W, start, ri_t, ro_t, n_out)
 
 
 def subm_conv(t, weight, bias, filter_size):

@@ -1,0 +1,99 @@
+"""Training step of the hot path's caller, without Lightning:
+``supervised_eventID.forward / training_step / calculate_loss / configure_optimizers``
+(/root/reference/src/utils/supervised_eventID.py:53-91,168-207) and
+``init_optimizer`` Adam(lr=1.0 x schedule, eps=1e-6, betas=(0.8,0.9), weight_decay)
+(/root/reference/src/utils/training_utils.py:12-13), LR schedule "standard"
+(/root/reference/src/utils/learning_rate_scheduler.py:92-126).
+"""
+import math
+
+import numpy as np
+import torch
+
+from .config import IMAGE_SIZE, OUTPUT_SHAPE, Config
+from .data import larcvsparse_to_scnsparse_2d, larcvsparse_to_scnsparse_3d
+from .distributed import FlatArena
+from .loss import accuracy, focal_loss
+from .networks import build_networks
+
+
+class WarmupFlatDecay:
+    """learning_rate_scheduler.py:92-126: linear warm-up (1 epoch) -> flat -> exponential decay."""
+
+    def __init__(self, peak_learning_rate=3e-3, decay_floor=1e-3, epoch_length=100, decay_epochs=5, total_epochs=25):
+        self.peak, self.floor, self.epoch_length = peak_learning_rate, decay_floor, epoch_length
+        self.flat_len = (total_epochs - decay_epochs - 1) * epoch_length
+        self.decay_len = decay_epochs * epoch_length
+
+    def __getitem__(self, idx):
+        if idx < self.epoch_length:
+            return 0.00001 + idx * (self.peak - 0.00001) / self.epoch_length
+        idx -= self.epoch_length
+        if idx < self.flat_len:
+            return self.peak
+        idx -= self.flat_len
+        if idx < self.decay_len:
+            return (self.peak - self.floor) * math.exp(-0.01 * idx) + self.floor
+        return 0.0
+
+    __call__ = __getitem__
+
+
+class Trainer:
+    """Owns encoder + heads (reference topology), the flat parameter/gradient arenas and Adam."""
+
+    def __init__(self, cfg=None, image_size=None, output_shape=None, weight_decay=1e-6, lr_schedule=None,
+                 device="cuda", seed=0):
+        self.cfg = cfg or Config()
+        self.image_size = image_size or IMAGE_SIZE["dune3d" if self.cfg.data.dimension == 3 else "dune2d"]
+        torch.manual_seed(seed)
+        self.encoder, self.head = build_networks(self.cfg, self.image_size, output_shape or OUTPUT_SHAPE)
+        self.encoder.to(device)
+        self.head.to(device)
+        self.arena = FlatArena([self.encoder, self.head])
+        self.flat_param = torch.nn.Parameter(self.arena.flat, requires_grad=True)
+        self.flat_param.grad = self.arena.grad
+        # Adam on ONE flat tensor == Adam on every parameter (elementwise), one fused kernel
+        self.opt = torch.optim.Adam([self.flat_param], lr=1.0, eps=1e-6, betas=(0.8, 0.9),
+                                    weight_decay=weight_decay, fused=torch.cuda.is_available())
+        self.lr_schedule = lr_schedule or WarmupFlatDecay()
+        self.global_step = 0
+        self.device = device
+
+    def to_scn_input(self, larcv_array):
+        if self.cfg.data.dimension == 3:
+            return larcvsparse_to_scnsparse_3d(larcv_array)
+        return larcvsparse_to_scnsparse_2d(larcv_array)
+
+    def stage(self, scn_input, labels):
+        """Host tuple -> device tensors (the Lightning 'batch -> device' step)."""
+        coords, feats, bs = scn_input
+        c = torch.as_tensor(np.asarray(coords)).to(self.device).to(torch.int32)
+        f = torch.as_tensor(np.asarray(feats), dtype=torch.float32).to(self.device)
+        lab = {k: torch.as_tensor(v).to(self.device) for k, v in labels.items()}
+        return (c, f, bs), lab
+
+    def forward(self, image):
+        return self.head(self.encoder(image))
+
+    def train_step(self, image, labels):
+        """forward + focal loss + backward + gradient all-reduce + Adam step. Returns loss tensor."""
+        self.arena.zero_grad()
+        logits = self.forward(image)
+        loss = focal_loss(logits, labels)
+        loss.backward()
+        self.arena.all_reduce_mean()
+        for g in self.opt.param_groups:
+            g["lr"] = self.lr_schedule[self.global_step]
+        self.opt.step()
+        self.global_step += 1
+        return loss.detach(), logits
+
+    @torch.no_grad()
+    def eval_step(self, image, labels=None):
+        self.encoder.eval(); self.head.eval()
+        logits = self.forward(image)
+        self.encoder.train(); self.head.train()
+        if labels is None:
+            return logits
+        return logits, accuracy(logits, labels)
