@@ -163,8 +163,10 @@ int sei_metadata_create(sei_metadata_t **out) {
 void sei_metadata_destroy(sei_metadata_t *m) {
     if (!m) return;
     for (auto *rb : m->rulebooks) {
-        free_tiled(rb->fwd);
-        if (!rb->submanifold) free_tiled(rb->bwd);
+        for (int v = 0; v < SEI_NVARIANT; v++) {
+            free_tiled(rb->fwd[v]);
+            free_tiled(rb->bwd[v]);
+        }
         delete rb;
     }
     for (auto *l : m->levels) free_level(l);
@@ -239,7 +241,9 @@ int sei_subm_rulebook(sei_metadata_t *m, const int32_t spatial[3], const int32_t
         rb->size[d] = filter[d];
         rb->stride[d] = 1;
     }
-    int rc = build_subm_rules(l, filter, &rb->fwd, (hipStream_t)stream);
+    rb->lin = rb->lout = l;
+    const TiledRules *t;
+    int rc = get_tiled(rb, false, 256, &t, (hipStream_t)stream);
     if (rc) {
         delete rb;
         return rc;
@@ -267,7 +271,9 @@ int sei_conv_rulebook(sei_metadata_t *m, const int32_t spatial_in[3], const int3
         rb->size[d] = size[d];
         rb->stride[d] = stride[d];
     }
-    int rc = build_strided(m, l, size, stride, m->batch_size, rb, (hipStream_t)stream);
+    int rc = build_strided_level(m, l, size, stride, rb, (hipStream_t)stream);
+    const TiledRules *t;
+    if (!rc) rc = get_tiled(rb, false, 256, &t, (hipStream_t)stream);
     if (rc) {
         delete rb;
         return rc;
@@ -278,15 +284,20 @@ int sei_conv_rulebook(sei_metadata_t *m, const int32_t spatial_in[3], const int3
     return 0;
 }
 
-int sei_rulebook_info(const sei_rulebook_t *rb, int64_t info[6]) {
-    info[0] = rb->fwd.n_dst; info[1] = rb->fwd.n_src; info[2] = rb->fwd.K;
-    info[3] = rb->fwd.n_rules; info[4] = rb->fwd.n_chunks; info[5] = rb->fwd.n_tiles;
+int sei_rulebook_info(const sei_rulebook_t *rb_c, int64_t info[8]) {
+    sei_rulebook_t *rb = const_cast<sei_rulebook_t *>(rb_c);
+    const TiledRules *t;
+    SEI_TRY(get_any_tiled(rb, false, &t, nullptr));
+    info[0] = t->n_dst; info[1] = t->n_src; info[2] = t->K; info[3] = t->n_rules;
+    info[4] = t->n_sub; info[5] = t->n_tiles; info[6] = t->n_sub; info[7] = t->tile_rows;
     return 0;
 }
 
 int sei_rulebook_export(sei_rulebook_t *rb, int64_t *start_host, int32_t *rules_in_dev, int32_t *rules_out_dev,
                         sei_stream_t stream) {
-    return export_rules(rb->fwd, start_host, rules_in_dev, rules_out_dev, (hipStream_t)stream);
+    const TiledRules *t;
+    SEI_TRY(get_any_tiled(rb, false, &t, (hipStream_t)stream));
+    return export_rules(*t, start_host, rules_in_dev, rules_out_dev, (hipStream_t)stream);
 }
 
 static double conv_bytes(const TiledRules &t, int nIn, int nOut) {
@@ -296,22 +307,27 @@ static double conv_bytes(const TiledRules &t, int nIn, int nOut) {
 int sei_conv_forward(sei_rulebook_t *rb, const float *X, const float *W, const float *bias, float *Y, int32_t nIn,
                      int32_t nOut, sei_stream_t stream) {
     if (!rb) SEI_FAIL("null rulebook");
-    const TiledRules &t = rb->fwd;
-    ProfScope ps(PROF_CONV_FWD, (hipStream_t)stream, 2.0 * t.n_rules * nIn * nOut, conv_bytes(t, nIn, nOut));
-    return conv_forward(t, false, X, W, bias, Y, nIn, nOut, (hipStream_t)stream);
+    hipStream_t st = (hipStream_t)stream;
+    const TiledRules *t;
+    SEI_TRY(get_tiled(rb, false, conv_tile_rows(nIn, nOut), &t, st));
+    ProfScope ps(PROF_CONV_FWD, st, 2.0 * t->n_rules * nIn * nOut, conv_bytes(*t, nIn, nOut));
+    return conv_forward(*t, X, W, bias, Y, nIn, nOut, st);
 }
 
 int sei_conv_backward_input(sei_rulebook_t *rb, const float *dY, const float *W, float *dX, int32_t nIn, int32_t nOut,
                             sei_stream_t stream) {
     if (!rb) SEI_FAIL("null rulebook");
     hipStream_t st = (hipStream_t)stream;
-    const TiledRules &t = rb->submanifold ? rb->fwd : rb->bwd;
-    ProfScope ps(PROF_CONV_BWD_IN, st, 2.0 * t.n_rules * nIn * nOut, conv_bytes(t, nOut, nIn));
-    float *Wt;
-    SEI_TRY(pool_alloc_t(&Wt, (size_t)t.K * nIn * nOut));
-    int rc = conv_transform_weights(W, Wt, t.K, nIn, nOut, rb->submanifold, st);
+    const TiledRules *t;
     // roles swap: contraction over nOut, result has nIn columns
-    if (!rc) rc = conv_forward(t, false, dY, Wt, nullptr, dX, nOut, nIn, st);
+    SEI_TRY(get_tiled(rb, true, conv_tile_rows(nOut, nIn), &t, st));
+    float *Wt;
+    SEI_TRY(pool_alloc_t(&Wt, (size_t)t->K * nIn * nOut));
+    int rc = conv_transform_weights(W, Wt, t->K, nIn, nOut, rb->submanifold, st);
+    if (!rc) {
+        ProfScope ps(PROF_CONV_BWD_IN, st, 2.0 * t->n_rules * nIn * nOut, conv_bytes(*t, nOut, nIn));
+        rc = conv_forward(*t, dY, Wt, nullptr, dX, nOut, nIn, st);
+    }
     pool_free(Wt);
     return rc;
 }
@@ -320,13 +336,14 @@ int sei_conv_backward_weight(sei_rulebook_t *rb, const float *X, const float *dY
                              int32_t nOut, sei_stream_t stream) {
     if (!rb) SEI_FAIL("null rulebook");
     hipStream_t st = (hipStream_t)stream;
-    const TiledRules &t = rb->fwd;
+    const TiledRules *t;
+    SEI_TRY(get_any_tiled(rb, false, &t, st));
     {
-        ProfScope ps(PROF_CONV_BWD_W, st, 2.0 * t.n_rules * nIn * nOut,
-                     4.0 * t.n_src * nIn + 4.0 * t.n_dst * nOut + 8.0 * t.n_rules + 4.0 * t.K * nIn * nOut);
-        SEI_TRY(conv_backward_weight(t, X, dY, dW, nIn, nOut, st));
+        ProfScope ps(PROF_CONV_BWD_W, st, 2.0 * t->n_rules * nIn * nOut,
+                     4.0 * t->n_src * nIn + 4.0 * t->n_dst * nOut + 8.0 * t->n_rules + 4.0 * t->K * nIn * nOut);
+        SEI_TRY(conv_backward_weight(*t, X, dY, dW, nIn, nOut, st));
     }
-    if (dbias) SEI_TRY(colsum(dY, t.n_dst, nOut, dbias, st));
+    if (dbias) SEI_TRY(colsum(dY, t->n_dst, nOut, dbias, st));
     return 0;
 }
 

@@ -81,34 +81,44 @@ struct Level {
 };
 
 // ---------------------------------------------------------------- rulebook
-constexpr int TILE_ROWS = 64;    // dst rows per wave-tile (one lane per row while building)
-constexpr int CHUNK_SLOTS = 32;  // rule slots per chunk = two MFMA sub-chunks of 16 rules
+constexpr int SUB_SLOTS = 16;  // rule slots per sub-chunk = rows of one v_mfma_f32_16x16x4_f32
 
-// Rules organised for output-stationary execution: dst rows are cut into wave-tiles of 64
-// consecutive rows; within a tile the rules are grouped by filter offset k and padded to
-// chunks of 32 slots (src = -1 marks padding).  One wavefront owns one tile.
+// Rules organised for output-stationary execution: dst rows are cut into tiles of `tile_rows`
+// (256 or 128) consecutive rows, one workgroup per tile; within a tile the rules are grouped by
+// filter offset k, compacted, and padded to sub-chunks of 16 slots (src = -1 marks padding).
 struct TiledRules {
     int64_t n_dst = 0, n_src = 0;
     int32_t K = 0;
+    int32_t tile_rows = 0;
     int32_t n_tiles = 0;
-    int64_t n_chunks = 0;
+    int64_t n_sub = 0;                  // sub-chunks (MFMA row blocks executed)
     int64_t n_rules = 0;
-    int64_t n_sub = 0;                    // non-empty 16-slot sub-chunks (executed MFMA row blocks)
-    int32_t *tile_chunk_start = nullptr;  // [n_tiles+1]
-    int32_t *chunk_src = nullptr;         // [n_chunks*32] src row or -1
-    uint8_t *chunk_dst = nullptr;         // [n_chunks*32] dst row local to tile
-    uint8_t *chunk_k = nullptr;           // [n_chunks]
-    int32_t *seg_start = nullptr;         // [(K+1)*n_tiles] k-major: first chunk (tile-relative) of offset k
+    int32_t *tile_sub_start = nullptr;  // [n_tiles+1] first sub-chunk of tile
+    int32_t *tile_seg = nullptr;        // [n_tiles][K+1] tile-relative sub-chunk offset where offset k begins
+    int32_t *seg_start = nullptr;       // [(K+1)][n_tiles] same, k-major (dW walks one k over many tiles)
+    int32_t *sub_src = nullptr;         // [n_sub*16] src row or -1
+    uint8_t *sub_dst = nullptr;         // [n_sub*16] dst row local to tile
+    bool built = false;
 };
 void free_tiled(TiledRules &t);
 
+struct ProbeGeom {
+    int mode;        // 0 submanifold, 1 strided forward (dst = out sites), 2 strided transposed (dst = in sites)
+    int f0, f1, f2;  // filter size
+    int t0, t1, t2;  // stride
+    int s0, s1, s2;  // spatial size of the SRC level
+};
+
 }  // namespace sei
 
+constexpr int SEI_NVARIANT = 2;  // tile_rows 256 / 128
 struct sei_rulebook {
-    sei::TiledRules fwd;      // dst = output rows, src = input rows
-    sei::TiledRules bwd;      // dst = input rows,  src = output rows (strided conv only)
-    bool submanifold = true;  // bwd == fwd with mirrored k
+    sei::TiledRules fwd[SEI_NVARIANT];  // dst = output rows, src = input rows
+    sei::TiledRules bwd[SEI_NVARIANT];  // dst = input rows,  src = output rows (strided conv only)
+    bool submanifold = true;            // bwd == fwd with mirrored k
     int32_t spatial_in[3], spatial_out[3], size[3], stride[3];
+    sei::Level *lin = nullptr, *lout = nullptr;
+    std::mutex mu;
 };
 
 struct sei_metadata {
@@ -136,13 +146,18 @@ int input_features_fwd(sei_metadata *m, const float *in, int C, float *out, hipS
 int input_features_bwd(sei_metadata *m, const float *dout, int C, float *din, hipStream_t st);
 int exclusive_scan_i32(const int32_t *in, int32_t *out, int64_t n, int32_t *total_dev, hipStream_t st);
 // rulebook.hip
-int build_subm_rules(Level *lv, const int32_t filter[3], TiledRules *out, hipStream_t st);
-int build_strided(sei_metadata *m, Level *lin, const int32_t size[3], const int32_t stride[3], int32_t batch,
-                  sei_rulebook *rb, hipStream_t st);
+inline int variant_of(int tile_rows) { return tile_rows == 256 ? 0 : 1; }
+// returns the (lazily built) tiled rules of the rulebook: transposed=false -> fwd, true -> bwd
+int get_tiled(sei_rulebook *rb, bool transposed, int tile_rows, const TiledRules **out, hipStream_t st);
+// any already-built variant (prefers 256 rows), building the 256 one if none exists
+int get_any_tiled(sei_rulebook *rb, bool transposed, const TiledRules **out, hipStream_t st);
+int build_strided_level(sei_metadata *m, Level *lin, const int32_t size[3], const int32_t stride[3], sei_rulebook *rb,
+                        hipStream_t st);
 int export_rules(const TiledRules &t, int64_t *start_host, int32_t *rin, int32_t *rout, hipStream_t st);
 // conv.hip
-int conv_forward(const TiledRules &t, bool flip_k, const float *X, const float *W, const float *bias, float *Y, int nIn,
-                 int nOut, hipStream_t st);
+int conv_tile_rows(int nIn, int nOut);  // tile size the forward kernel wants for these plane counts
+int conv_forward(const TiledRules &t, const float *X, const float *W, const float *bias, float *Y, int nIn, int nOut,
+                 hipStream_t st);
 int conv_transform_weights(const float *W, float *Wt, int K, int nIn, int nOut, bool flip, hipStream_t st);
 int conv_backward_weight(const TiledRules &t, const float *X, const float *dY, float *dW, int nIn, int nOut,
                          hipStream_t st);

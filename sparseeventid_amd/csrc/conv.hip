@@ -1,15 +1,18 @@
 // Sparse convolution arithmetic for gfx950 (scn.SubmanifoldConvolution / scn.Convolution:
 // resnet.py:30-50,105-110; sparse_building_blocks.py:29-34,110-117).
 //
-// Output-stationary gather -> MFMA -> LDS-accumulate:
-//   one wavefront owns a tile of 64 dst rows whose fp32 accumulators live in LDS;
-//   it walks the tile's rule chunks (<=32 rules of ONE filter offset k, compacted),
-//   gathers the src feature rows straight into MFMA A-operand registers (float4 per lane,
-//   coalesced 64 B per rule row), multiplies by W[k] with v_mfma_f32_16x16x4_f32 (exact fp32)
-//   and adds the 16xN result rows into the LDS tile (ds_add_f32, rows are wave-private).
-//   Each dst row is written to HBM exactly once (no global atomics, run-to-run deterministic).
-// dW: per (k, split) workgroup reduces X[src]^T dY[dst] over its rule chunks with the same
-//   MFMA (rules are the contraction dimension), partial slabs are summed in a fixed order.
+// Forward / dX: output-stationary  gather -> MFMA -> LDS-accumulate.
+//   One 256-thread workgroup owns a tile of 256 (or 128) dst rows whose fp32 accumulators live in
+//   LDS.  It walks the filter offsets k; for each k the tile's rules are compacted into sub-chunks
+//   of 16 rules that are dealt round-robin to the wavefronts.  W[k] is streamed through LDS in
+//   slices of 16/32 input planes (double buffered, one barrier per slice) and shared by all waves;
+//   src feature rows are gathered straight into MFMA A-operand registers (float4 per lane, 64 B
+//   per rule row and step), multiplied with v_mfma_f32_16x16x4_f32 (exact fp32) and the 16xN
+//   results are added into the LDS tile (ds_add_f32; rows of one k are distinct and the k-phases
+//   are barrier-separated, so the sum order is fixed: run-to-run deterministic, no global atomics).
+//   Every dst row is written to HBM exactly once.
+// dW: per (k, split) workgroup reduces X[src]^T dY[dst] over its sub-chunks with the same MFMA
+//   (rules are the contraction dimension); partial slabs are summed in a fixed order.
 #include "common.h"
 
 namespace sei {
@@ -22,169 +25,227 @@ __device__ inline void lds_add(float *p, float v) {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-struct ChunkIdx {
-    int src0, src1, d0, d1, k;
-};
-
-__device__ inline ChunkIdx load_chunk(const int32_t *__restrict__ chunk_src, const uint8_t *__restrict__ chunk_dst,
-                                      const uint8_t *__restrict__ chunk_k, int64_t c, int r16) {
-    ChunkIdx ci;
-    ci.src0 = chunk_src[c * CHUNK_SLOTS + r16];
-    ci.src1 = chunk_src[c * CHUNK_SLOTS + 16 + r16];
-    ci.d0 = chunk_dst[c * CHUNK_SLOTS + r16];
-    ci.d1 = chunk_dst[c * CHUNK_SLOTS + 16 + r16];
-    ci.k = chunk_k[c];
-    return ci;
-}
-
 __device__ inline float4 load_a(const float *__restrict__ X, int src, int CIN, int off) {
     if (src >= 0) return *reinterpret_cast<const float4 *>(X + (size_t)src * CIN + off);
     return make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
-// NT = 16-column tiles per wave.  colsplit waves share one dst tile (disjoint column ranges).
-template <int NT>
+constexpr int MAXS = 4;  // sub-chunks of one offset a wave can own: tile_rows / 16 / units
+
+// NT  = 16-column tiles per wave, CS = waves sharing one sub-chunk (column split), SLJ = slice / 16.
+// tile_rows = 256 / CS.  LDS: acc[tile_rows][COUT] | wbuf[2][SL][COUT] | seg[K+1]
+template <int NT, int CS, int SLJ>
 __global__ __launch_bounds__(256) void conv_tile_mfma_kernel(
     const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ Y,
-    const int32_t *__restrict__ tile_chunk_start, const int32_t *__restrict__ chunk_src,
-    const uint8_t *__restrict__ chunk_dst, const uint8_t *__restrict__ chunk_k, int n_tiles, int64_t n_dst, int CIN,
-    int COUT, int colsplit) {
+    const int32_t *__restrict__ tile_sub_start, const int32_t *__restrict__ tile_seg,
+    const int32_t *__restrict__ sub_src, const uint8_t *__restrict__ sub_dst, int64_t n_dst, int K, int CIN, int COUT) {
     extern __shared__ float lds[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int tiles_per_wg = 4 / colsplit;
-    const int tw = wave / colsplit, cg = wave - tw * colsplit;
-    const int tile = blockIdx.x * tiles_per_wg + tw;
-    if (tile >= n_tiles) return;  // no barriers below: waves are independent
-    const int col0 = cg * NT * 16;
+    constexpr int TR = 256 / CS;
+    constexpr int U = 4 / CS;  // units (groups of CS waves) dealing sub-chunks
+    constexpr int SL = 16 * SLJ;
     constexpr int NC = NT * 16;
-    float *acc = lds + (size_t)tw * TILE_ROWS * COUT;
+    const int tile = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int unit = wave / CS, cg = wave - unit * CS;
+    const int col0 = cg * NC;
     const int r16 = lane & 15, g = lane >> 4;
+    float *acc_tile = lds;
+    float *wbuf = lds + (size_t)TR * COUT;
+    int *seg = reinterpret_cast<int *>(wbuf + 2 * SL * COUT);
 
-    for (int idx = lane; idx < TILE_ROWS * NC; idx += 64) {
-        int r = idx / NC, c = idx - r * NC;
-        acc[r * COUT + col0 + c] = bias ? bias[col0 + c] : 0.f;
+    for (int i = threadIdx.x; i <= K; i += 256) seg[i] = tile_seg[(size_t)tile * (K + 1) + i];
+    {
+        const int V = COUT >> 2;
+        for (int idx = threadIdx.x; idx < TR * V; idx += 256) {
+            int v = idx % V;
+            float4 b = bias ? *reinterpret_cast<const float4 *>(bias + 4 * v) : make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4 *>(acc_tile + (size_t)idx * 4) = b;
+        }
     }
+    __syncthreads();
 
-    const int c0 = tile_chunk_start[tile], c1 = tile_chunk_start[tile + 1];
-    const int J = CIN >> 4;
-    if (c0 < c1) {
-        ChunkIdx cur = load_chunk(chunk_src, chunk_dst, chunk_k, c0, r16);
-        ChunkIdx nxt = cur;
-        if (c0 + 1 < c1) nxt = load_chunk(chunk_src, chunk_dst, chunk_k, c0 + 1, r16);
-        float4 a0 = load_a(X, cur.src0, CIN, 4 * g), a1 = load_a(X, cur.src1, CIN, 4 * g);
-        for (int c = c0; c < c1; c++) {
-            const bool has1 = __any(cur.src1 >= 0);
-            const float *Wk = W + (size_t)cur.k * CIN * COUT + col0 + r16;
-            f32x4 acc0[NT], acc1[NT];
+    const int64_t sub0 = tile_sub_start[tile];
+    const int NS = CIN / SL;              // slices per offset
+    const int slice_f4 = SL * COUT / 4;   // float4 per slice (contiguous in W)
+    // staging registers: each thread copies up to 3 float4 of a slice (SL*COUT/4 <= 768*... checked on host)
+    constexpr int STG = 3 * SLJ > 6 ? 6 : 3 * SLJ;
+    float4 wreg[STG];
+
+    auto stage_issue = [&](int k, int s) {
+        const float4 *src = reinterpret_cast<const float4 *>(W + ((size_t)k * CIN + (size_t)s * SL) * COUT);
 #pragma unroll
-            for (int n = 0; n < NT; n++) {
-                acc0[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                acc1[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < STG; q++) {
+            int i = threadIdx.x + q * 256;
+            if (i < slice_f4) wreg[q] = src[i];
+        }
+    };
+    auto stage_commit = [&](int buf) {
+        float4 *dst = reinterpret_cast<float4 *>(wbuf + (size_t)buf * SL * COUT);
+#pragma unroll
+        for (int q = 0; q < STG; q++) {
+            int i = threadIdx.x + q * 256;
+            if (i < slice_f4) dst[i] = wreg[q];
+        }
+    };
+    auto next_k = [&](int k) {
+        k++;
+        while (k < K && seg[k + 1] == seg[k]) k++;
+        return __builtin_amdgcn_readfirstlane(k);
+    };
+
+    int src_c[MAXS], dst_c[MAXS], src_n[MAXS], dst_n[MAXS];
+    int ms_c = 0, ms_n = 0;
+    auto load_idx = [&](int k, int *srcs, int *dsts) {
+        int s0 = __builtin_amdgcn_readfirstlane(seg[k]), ns = __builtin_amdgcn_readfirstlane(seg[k + 1]) - s0;
+        int ms = 0;
+#pragma unroll
+        for (int m = 0; m < MAXS; m++) {
+            int s = unit + m * U;
+            if (s < ns) {
+                int64_t slot = (sub0 + s0 + s) * SUB_SLOTS + r16;
+                srcs[m] = sub_src[slot];
+                dsts[m] = sub_dst[slot];
+                ms = m + 1;
+            } else {
+                srcs[m] = -1;
+                dsts[m] = 0;
             }
-            for (int j = 0; j < J; j++) {
-                float4 a0n, a1n;
-                if (j + 1 < J) {
-                    a0n = load_a(X, cur.src0, CIN, 16 * (j + 1) + 4 * g);
-                    a1n = load_a(X, cur.src1, CIN, 16 * (j + 1) + 4 * g);
-                } else {
-                    a0n = load_a(X, c + 1 < c1 ? nxt.src0 : -1, CIN, 4 * g);
-                    a1n = load_a(X, c + 1 < c1 ? nxt.src1 : -1, CIN, 4 * g);
+        }
+        return __builtin_amdgcn_readfirstlane(ms);
+    };
+
+    int k = next_k(-1);
+    if (k < K) {
+        ms_c = load_idx(k, src_c, dst_c);
+        stage_issue(k, 0);
+        float4 a_c[MAXS][SLJ], a_n[MAXS][SLJ];
+#pragma unroll
+        for (int m = 0; m < MAXS; m++)
+#pragma unroll
+            for (int jj = 0; jj < SLJ; jj++) a_n[m][jj] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int m = 0; m < MAXS; m++)
+#pragma unroll
+            for (int jj = 0; jj < SLJ; jj++) a_c[m][jj] = load_a(X, src_c[m], CIN, 16 * jj + 4 * g);
+        int phase = 0;
+        while (k < K) {
+            const int kn = next_k(k);
+            if (kn < K) ms_n = load_idx(kn, src_n, dst_n);
+            f32x4 acc[MAXS][NT];
+#pragma unroll
+            for (int m = 0; m < MAXS; m++)
+#pragma unroll
+                for (int n = 0; n < NT; n++) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int s = 0; s < NS; s++) {
+                stage_commit(phase & 1);
+                __syncthreads();
+                // prefetch the next phase's weight slice and A fragments while this one computes
+                if (s + 1 < NS) {
+                    stage_issue(k, s + 1);
+#pragma unroll
+                    for (int m = 0; m < MAXS; m++)
+#pragma unroll
+                        for (int jj = 0; jj < SLJ; jj++)
+                            a_n[m][jj] = load_a(X, src_c[m], CIN, (s + 1) * SL + 16 * jj + 4 * g);
+                } else if (kn < K) {
+                    stage_issue(kn, 0);
+#pragma unroll
+                    for (int m = 0; m < MAXS; m++)
+#pragma unroll
+                        for (int jj = 0; jj < SLJ; jj++) a_n[m][jj] = load_a(X, src_n[m], CIN, 16 * jj + 4 * g);
                 }
-                const float *wrow = Wk + (size_t)(16 * j + 4 * g) * COUT;
-                const float av0[4] = {a0.x, a0.y, a0.z, a0.w};
-                const float av1[4] = {a1.x, a1.y, a1.z, a1.w};
-                if (has1) {
+                const float *wb = wbuf + (size_t)(phase & 1) * SL * COUT + col0 + r16;
+#pragma unroll
+                for (int jj = 0; jj < SLJ; jj++) {
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
+                        float b[NT];
 #pragma unroll
-                        for (int n = 0; n < NT; n++) {
-                            float b = wrow[(size_t)e * COUT + 16 * n];
-                            acc0[n] = mfma16(av0[e], b, acc0[n]);
-                            acc1[n] = mfma16(av1[e], b, acc1[n]);
-                        }
-                    }
-                } else {
+                        for (int n = 0; n < NT; n++) b[n] = wb[(16 * jj + 4 * g + e) * COUT + 16 * n];
 #pragma unroll
-                    for (int e = 0; e < 4; e++) {
+                        for (int m = 0; m < MAXS; m++) {
+                            if (m < ms_c) {
+                                const float av = e == 0 ? a_c[m][jj].x : e == 1 ? a_c[m][jj].y : e == 2 ? a_c[m][jj].z : a_c[m][jj].w;
 #pragma unroll
-                        for (int n = 0; n < NT; n++) {
-                            float b = wrow[(size_t)e * COUT + 16 * n];
-                            acc0[n] = mfma16(av0[e], b, acc0[n]);
+                                for (int n = 0; n < NT; n++) acc[m][n] = mfma16(av, b[n], acc[m][n]);
+                            }
                         }
                     }
                 }
-                a0 = a0n;
-                a1 = a1n;
+#pragma unroll
+                for (int m = 0; m < MAXS; m++)
+#pragma unroll
+                    for (int jj = 0; jj < SLJ; jj++) a_c[m][jj] = a_n[m][jj];
+                phase++;
             }
             // D[row = 4g+i][col = r16] belongs to rule slot 4g+i of the sub-chunk
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                int s0 = __shfl(cur.src0, 4 * g + i), dd0 = __shfl(cur.d0, 4 * g + i);
-                if (s0 >= 0) {
-                    float *p = acc + dd0 * COUT + col0 + r16;
+            for (int m = 0; m < MAXS; m++) {
+                if (m < ms_c) {
 #pragma unroll
-                    for (int n = 0; n < NT; n++) lds_add(p + 16 * n, acc0[n][i]);
-                }
-            }
-            if (has1) {
+                    for (int i = 0; i < 4; i++) {
+                        int sr = __shfl(src_c[m], 4 * g + i), dd = __shfl(dst_c[m], 4 * g + i);
+                        if (sr >= 0) {
+                            float *p = acc_tile + dd * COUT + col0 + r16;
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    int s1 = __shfl(cur.src1, 4 * g + i), dd1 = __shfl(cur.d1, 4 * g + i);
-                    if (s1 >= 0) {
-                        float *p = acc + dd1 * COUT + col0 + r16;
-#pragma unroll
-                        for (int n = 0; n < NT; n++) lds_add(p + 16 * n, acc1[n][i]);
+                            for (int n = 0; n < NT; n++) lds_add(p + 16 * n, acc[m][n][i]);
+                        }
                     }
                 }
             }
-            cur = nxt;
-            if (c + 2 < c1) nxt = load_chunk(chunk_src, chunk_dst, chunk_k, c + 2, r16);
+#pragma unroll
+            for (int m = 0; m < MAXS; m++) {
+                src_c[m] = src_n[m];
+                dst_c[m] = dst_n[m];
+            }
+            ms_c = ms_n;
+            k = kn;
         }
     }
+    __syncthreads();
     // epilogue: every dst row is written once, as whole float4 row segments
-    constexpr int V = NC / 4;
-    const int64_t row0 = (int64_t)tile * TILE_ROWS;
-    for (int idx = lane; idx < TILE_ROWS * V; idx += 64) {
-        int r = idx / V, v = idx - r * V;
-        if (row0 + r < n_dst) {
-            float4 val = *reinterpret_cast<const float4 *>(acc + r * COUT + col0 + 4 * v);
-            *reinterpret_cast<float4 *>(Y + (size_t)(row0 + r) * COUT + col0 + 4 * v) = val;
-        }
+    const int V = COUT >> 2;
+    const int64_t row0 = (int64_t)tile * TR;
+    for (int idx = threadIdx.x; idx < TR * V; idx += 256) {
+        int r = idx / V;
+        if (row0 + r < n_dst)
+            *reinterpret_cast<float4 *>(Y + (size_t)row0 * COUT + (size_t)idx * 4) =
+                *reinterpret_cast<const float4 *>(acc_tile + (size_t)idx * 4);
     }
 }
 
-// Any channel counts (stem Cin=1, odd test sizes): same tile/chunk walk, scalar FMA.
-__global__ __launch_bounds__(64) void conv_tile_generic_kernel(
+// Any channel counts (stem Cin=1, odd test sizes): same tile / sub-chunk walk, scalar FMA.
+__global__ __launch_bounds__(256) void conv_tile_generic_kernel(
     const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ Y,
-    const int32_t *__restrict__ tile_chunk_start, const int32_t *__restrict__ chunk_src,
-    const uint8_t *__restrict__ chunk_dst, const uint8_t *__restrict__ chunk_k, int n_tiles, int64_t n_dst, int CIN,
-    int COUT) {
+    const int32_t *__restrict__ tile_sub_start, const int32_t *__restrict__ tile_seg,
+    const int32_t *__restrict__ sub_src, const uint8_t *__restrict__ sub_dst, int64_t n_dst, int K, int CIN, int COUT,
+    int TR) {
     extern __shared__ float lds[];
-    const int lane = threadIdx.x;
     const int tile = blockIdx.x;
     float *acc = lds;
-    for (int idx = lane; idx < TILE_ROWS * COUT; idx += 64) acc[idx] = bias ? bias[idx % COUT] : 0.f;
+    for (int idx = threadIdx.x; idx < TR * COUT; idx += 256) acc[idx] = bias ? bias[idx % COUT] : 0.f;
     __syncthreads();
-    const int c0 = tile_chunk_start[tile], c1 = tile_chunk_start[tile + 1];
+    const int64_t sub0 = tile_sub_start[tile];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r16 = lane & 15, g = lane >> 4;
-    for (int c = c0; c < c1; c++) {
-        const int k = chunk_k[c];
+    for (int k = 0; k < K; k++) {
+        const int s0 = tile_seg[(size_t)tile * (K + 1) + k], s1 = tile_seg[(size_t)tile * (K + 1) + k + 1];
         const float *Wk = W + (size_t)k * CIN * COUT;
-        for (int sub = 0; sub < 2; sub++) {
-            int src = chunk_src[(int64_t)c * CHUNK_SLOTS + 16 * sub + r16];
-            int d = chunk_dst[(int64_t)c * CHUNK_SLOTS + 16 * sub + r16];
+        for (int s = s0 + wave; s < s1; s += 4) {
+            int64_t slot = (sub0 + s) * SUB_SLOTS + r16;
+            int src = sub_src[slot], d = sub_dst[slot];
             if (src < 0) continue;
             const float *xr = X + (size_t)src * CIN;
             for (int co = g; co < COUT; co += 4) {
-                float s = 0.f;
-                for (int ci = 0; ci < CIN; ci++) s = fmaf(xr[ci], Wk[(size_t)ci * COUT + co], s);
-                lds_add(&acc[d * COUT + co], s);
+                float sum = 0.f;
+                for (int ci = 0; ci < CIN; ci++) sum = fmaf(xr[ci], Wk[(size_t)ci * COUT + co], sum);
+                lds_add(&acc[d * COUT + co], sum);
             }
         }
+        __syncthreads();  // keeps the per-row sum order fixed (k-phases), as in the MFMA kernel
     }
-    __syncthreads();
-    const int64_t row0 = (int64_t)tile * TILE_ROWS;
-    for (int idx = lane; idx < TILE_ROWS * COUT; idx += 64) {
+    const int64_t row0 = (int64_t)tile * TR;
+    for (int idx = threadIdx.x; idx < TR * COUT; idx += 256) {
         int r = idx / COUT;
         if (row0 + r < n_dst) Y[(size_t)row0 * COUT + idx] = acc[idx];
     }
@@ -195,66 +256,94 @@ __global__ void fill_bias_kernel(float *Y, int64_t n, int C, const float *bias) 
     if (t < n * C) Y[t] = bias ? bias[t % C] : 0.f;
 }
 
-template <int NT>
-static int launch_mfma(const TiledRules &t, const float *X, const float *W, const float *bias, float *Y, int nIn,
-                       int nOut, int colsplit, hipStream_t st) {
+struct FwdPlan {
+    bool mfma;
+    int nt, cs, slj, tile_rows;
+    size_t lds_bytes;
+};
+
+static size_t fwd_lds(int tile_rows, int nOut, int slj, int K) {
+    return ((size_t)tile_rows * nOut + 2 * 16 * slj * nOut) * sizeof(float) + (K + 1) * sizeof(int);
+}
+
+static FwdPlan plan_forward(int nIn, int nOut, int K) {
+    FwdPlan p{};
+    p.mfma = (nIn % 16 == 0) && (nOut % 16 == 0) && nIn >= 16;
+    p.cs = 1;
+    p.nt = nOut / 16;
+    if (p.mfma && p.nt > 6) {
+        if (nOut % 32 == 0 && nOut / 32 <= 6) {
+            p.cs = 2;
+            p.nt = nOut / 32;
+        } else
+            p.mfma = false;
+    }
+    if (p.mfma) {
+        // the tile size may depend on nOut only (the rulebook variant is chosen from it): decide the
+        // column split with the worst-case slice (32 planes) and filter volume (125)
+        if (fwd_lds(256 / p.cs, nOut, 2, 125) > 160 * 1024 && p.cs == 1 && nOut % 32 == 0) {
+            p.cs = 2;
+            p.nt = nOut / 32;
+        }
+        p.tile_rows = 256 / p.cs;
+        p.slj = (nIn % 32 == 0) ? 2 : 1;
+        p.lds_bytes = fwd_lds(p.tile_rows, nOut, p.slj, K);
+        if (p.lds_bytes > 160 * 1024) p.mfma = false;
+    }
+    if (!p.mfma) {
+        p.tile_rows = (size_t)256 * nOut * sizeof(float) <= 96 * 1024 ? 256 : 128;
+        p.lds_bytes = (size_t)p.tile_rows * nOut * sizeof(float);
+    }
+    return p;
+}
+
+int conv_tile_rows(int nIn, int nOut) { return plan_forward(nIn, nOut, 27).tile_rows; }
+
+template <int NT, int CS, int SLJ>
+static int launch_mfma(const TiledRules &t, const FwdPlan &p, const float *X, const float *W, const float *bias,
+                       float *Y, int nIn, int nOut, hipStream_t st) {
     static bool attr_set = false;
-    size_t lds_bytes = (size_t)(4 / colsplit) * TILE_ROWS * nOut * sizeof(float);
     if (!attr_set) {
-        SEI_HIP(hipFuncSetAttribute((const void *)conv_tile_mfma_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    160 * 1024));
+        SEI_HIP(hipFuncSetAttribute((const void *)conv_tile_mfma_kernel<NT, CS, SLJ>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    int tiles_per_wg = 4 / colsplit;
-    int nb = (t.n_tiles + tiles_per_wg - 1) / tiles_per_wg;
-    conv_tile_mfma_kernel<NT><<<nb, 256, lds_bytes, st>>>(X, W, bias, Y, t.tile_chunk_start, t.chunk_src, t.chunk_dst,
-                                                          t.chunk_k, t.n_tiles, t.n_dst, nIn, nOut, colsplit);
+    conv_tile_mfma_kernel<NT, CS, SLJ><<<t.n_tiles, 256, p.lds_bytes, st>>>(
+        X, W, bias, Y, t.tile_sub_start, t.tile_seg, t.sub_src, t.sub_dst, t.n_dst, t.K, nIn, nOut);
     SEI_LAUNCH_CHECK();
     return 0;
 }
 
-int conv_forward(const TiledRules &t, bool /*unused*/, const float *X, const float *W, const float *bias, float *Y,
-                 int nIn, int nOut, hipStream_t st) {
+#define FWD_CASE(NT_, CS_, SLJ_) \
+    if (p.nt == NT_ && p.cs == CS_ && p.slj == SLJ_) return launch_mfma<NT_, CS_, SLJ_>(t, p, X, W, bias, Y, nIn, nOut, st);
+
+int conv_forward(const TiledRules &t, const float *X, const float *W, const float *bias, float *Y, int nIn, int nOut,
+                 hipStream_t st) {
     if (t.n_dst == 0) return 0;
-    if (t.n_chunks == 0) {
+    if (t.n_sub == 0) {
         int64_t tot = t.n_dst * nOut;
         fill_bias_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, st>>>(Y, t.n_dst, nOut, bias);
         SEI_LAUNCH_CHECK();
         return 0;
     }
-    bool mfma_ok = (nIn % 16 == 0) && (nOut % 16 == 0);
-    int colsplit = 1, nt = nOut / 16;
-    if (mfma_ok && nt > 6) {
-        if (nOut % 32 == 0 && nOut / 32 <= 6) {
-            colsplit = 2;
-            nt = nOut / 32;
-        } else if (nOut % 64 == 0 && nOut / 64 <= 6) {
-            colsplit = 4;
-            nt = nOut / 64;
-        } else
-            mfma_ok = false;
+    FwdPlan p = plan_forward(nIn, nOut, t.K);
+    if (p.tile_rows != t.tile_rows) SEI_FAIL("conv_forward: rulebook tile size does not match the kernel plan");
+    if (p.mfma) {
+        FWD_CASE(1, 1, 1) FWD_CASE(2, 1, 1) FWD_CASE(3, 1, 1) FWD_CASE(4, 1, 1) FWD_CASE(5, 1, 1) FWD_CASE(6, 1, 1)
+        FWD_CASE(1, 1, 2) FWD_CASE(2, 1, 2) FWD_CASE(3, 1, 2) FWD_CASE(4, 1, 2) FWD_CASE(5, 1, 2) FWD_CASE(6, 1, 2)
+        FWD_CASE(4, 2, 1) FWD_CASE(5, 2, 1) FWD_CASE(6, 2, 1) FWD_CASE(3, 2, 1)
+        FWD_CASE(4, 2, 2) FWD_CASE(5, 2, 2) FWD_CASE(6, 2, 2) FWD_CASE(3, 2, 2)
+        SEI_FAIL("conv_forward: no MFMA instantiation for this plan");
     }
-    if (mfma_ok && (size_t)(4 / colsplit) * TILE_ROWS * nOut * sizeof(float) > 160 * 1024) mfma_ok = false;
-    if (mfma_ok) {
-        switch (nt) {
-            case 1: return launch_mfma<1>(t, X, W, bias, Y, nIn, nOut, colsplit, st);
-            case 2: return launch_mfma<2>(t, X, W, bias, Y, nIn, nOut, colsplit, st);
-            case 3: return launch_mfma<3>(t, X, W, bias, Y, nIn, nOut, colsplit, st);
-            case 4: return launch_mfma<4>(t, X, W, bias, Y, nIn, nOut, colsplit, st);
-            case 5: return launch_mfma<5>(t, X, W, bias, Y, nIn, nOut, colsplit, st);
-            case 6: return launch_mfma<6>(t, X, W, bias, Y, nIn, nOut, colsplit, st);
-        }
-    }
-    size_t lds_bytes = (size_t)TILE_ROWS * nOut * sizeof(float);
-    if (lds_bytes > 160 * 1024) SEI_FAIL("conv: nOut too large for the generic kernel");
+    if (p.lds_bytes > 160 * 1024) SEI_FAIL("conv: nOut too large for the generic kernel");
     static bool attr_set = false;
     if (!attr_set) {
         SEI_HIP(hipFuncSetAttribute((const void *)conv_tile_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     160 * 1024));
         attr_set = true;
     }
-    conv_tile_generic_kernel<<<t.n_tiles, 64, lds_bytes, st>>>(X, W, bias, Y, t.tile_chunk_start, t.chunk_src,
-                                                              t.chunk_dst, t.chunk_k, t.n_tiles, t.n_dst, nIn, nOut);
+    conv_tile_generic_kernel<<<t.n_tiles, 256, p.lds_bytes, st>>>(X, W, bias, Y, t.tile_sub_start, t.tile_seg, t.sub_src,
+                                                                 t.sub_dst, t.n_dst, t.K, nIn, nOut, t.tile_rows);
     SEI_LAUNCH_CHECK();
     return 0;
 }
@@ -280,15 +369,50 @@ int conv_transform_weights(const float *W, float *Wt, int K, int nIn, int nOut, 
 }
 
 // ------------------------------------------------------------------------------------------ dW
-constexpr int DW_LIST_CAP = 2048;
+constexpr int DW_TILES_PER_ITER = 128;             // tiles scanned per list refill
+constexpr int DW_LIST_CAP = DW_TILES_PER_ITER * 16;  // <= 16 sub-chunks per (tile, k)
+
+// builds in LDS the list of (sub-chunk, tile) pairs of offset k for tiles [tb, tb+128) in tile order
+__device__ inline int dw_build_list(const int32_t *__restrict__ tile_sub_start, const int32_t *__restrict__ seg_start,
+                                    int n_tiles, int k, int tb, int t_end, int *list_sub, int *list_tile, int *scan_tmp) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t = tb + threadIdx.x;
+    int cnt = 0, base = 0;
+    if (threadIdx.x < DW_TILES_PER_ITER && t < t_end) {
+        int a = seg_start[(size_t)k * n_tiles + t], b = seg_start[(size_t)(k + 1) * n_tiles + t];
+        cnt = b - a;
+        base = tile_sub_start[t] + a;
+    }
+    int incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int v = __shfl_up(incl, d);
+        if (lane >= d) incl += v;
+    }
+    if (lane == 63) scan_tmp[wave] = incl;
+    __syncthreads();
+    int wbase = 0, total = 0;
+    for (int w = 0; w < 4; w++) {
+        int v = scan_tmp[w];
+        if (w < wave) wbase += v;
+        total += v;
+    }
+    int pos = wbase + incl - cnt;
+    for (int q = 0; q < cnt; q++) {
+        list_sub[pos + q] = base + q;
+        list_tile[pos + q] = t;
+    }
+    __syncthreads();
+    return total;
+}
 
 template <int MT, int NT>
 __global__ __launch_bounds__(256) void conv_dw_mfma_kernel(
-    const float *__restrict__ X, const float *__restrict__ dY, const int32_t *__restrict__ tile_chunk_start,
-    const int32_t *__restrict__ seg_start, const int32_t *__restrict__ chunk_src, const uint8_t *__restrict__ chunk_dst,
-    int n_tiles, int CIN, int COUT, int tiles_per_split, int S, float *__restrict__ slab) {
+    const float *__restrict__ X, const float *__restrict__ dY, const int32_t *__restrict__ tile_sub_start,
+    const int32_t *__restrict__ seg_start, const int32_t *__restrict__ sub_src, const uint8_t *__restrict__ sub_dst,
+    int n_tiles, int TR, int CIN, int COUT, int tiles_per_split, int S, float *__restrict__ slab) {
     extern __shared__ float lds_f[];
-    __shared__ int list_chunk[DW_LIST_CAP];
+    __shared__ int list_sub[DW_LIST_CAP];
     __shared__ int list_tile[DW_LIST_CAP];
     __shared__ int scan_tmp[8];
     const int k = blockIdx.x, s = blockIdx.y, cig = blockIdx.z;
@@ -303,45 +427,16 @@ __global__ __launch_bounds__(256) void conv_dw_mfma_kernel(
 
     const int t_begin = s * tiles_per_split;
     const int t_end = min(n_tiles, t_begin + tiles_per_split);
-    for (int tb = t_begin; tb < t_end; tb += 256) {
-        const int t = tb + threadIdx.x;
-        int cnt = 0, base = 0;
-        if (t < t_end) {
-            int a = seg_start[(size_t)k * n_tiles + t], b = seg_start[(size_t)(k + 1) * n_tiles + t];
-            cnt = b - a;
-            base = tile_chunk_start[t] + a;
-        }
-        // block exclusive scan of cnt
-        int incl = cnt;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            int v = __shfl_up(incl, d);
-            if (lane >= d) incl += v;
-        }
-        if (lane == 63) scan_tmp[wave] = incl;
-        __syncthreads();
-        int wbase = 0, total = 0;
-        for (int w = 0; w < 4; w++) {
-            int v = scan_tmp[w];
-            if (w < wave) wbase += v;
-            total += v;
-        }
-        int pos = wbase + incl - cnt;
-        for (int q = 0; q < cnt; q++)
-            if (pos + q < DW_LIST_CAP) {
-                list_chunk[pos + q] = base + q;
-                list_tile[pos + q] = t;
-            }
-        __syncthreads();
-        // a tile holds at most 2 chunks per offset (64 rows / 32 slots) -> total <= 512 <= DW_LIST_CAP
+    for (int tb = t_begin; tb < t_end; tb += DW_TILES_PER_ITER) {
+        const int total = dw_build_list(tile_sub_start, seg_start, n_tiles, k, tb, t_end, list_sub, list_tile, scan_tmp);
         for (int li = wave; li < total; li += 4) {
-            const int64_t c = list_chunk[li];
-            const int64_t rowbase = (int64_t)list_tile[li] * TILE_ROWS;
+            const int64_t c = list_sub[li];
+            const int64_t rowbase = (int64_t)list_tile[li] * TR;
 #pragma unroll 2
-            for (int q = 0; q < CHUNK_SLOTS / 4; q++) {
-                int src = chunk_src[c * CHUNK_SLOTS + 4 * q + g];
+            for (int q = 0; q < SUB_SLOTS / 4; q++) {
+                int src = sub_src[c * SUB_SLOTS + 4 * q + g];
                 if (!__any(src >= 0)) continue;
-                int dl = chunk_dst[c * CHUNK_SLOTS + 4 * q + g];
+                int dl = sub_dst[c * SUB_SLOTS + 4 * q + g];
                 float a[MT], b[NT];
                 const float *xr = X + (size_t)(src >= 0 ? src : 0) * CIN + ci0 + r16;
                 const float *yr = dY + (size_t)(rowbase + dl) * COUT + r16;
@@ -380,11 +475,59 @@ __global__ __launch_bounds__(256) void conv_dw_mfma_kernel(
     for (int idx = threadIdx.x; idx < MT * 16 * COUT; idx += 256) out[idx] = red[idx];
 }
 
+// dW for tiny nIn (stem: nIn = 1): HBM-bound gather of dY rows; lane = output plane, the 64/COUT lane groups
+// take different rule slots; fixed-order reductions.
+template <int CIN>
+__global__ __launch_bounds__(256) void conv_dw_smallcin_kernel(
+    const float *__restrict__ X, const float *__restrict__ dY, const int32_t *__restrict__ tile_sub_start,
+    const int32_t *__restrict__ seg_start, const int32_t *__restrict__ sub_src, const uint8_t *__restrict__ sub_dst,
+    int n_tiles, int TR, int COUT, int tiles_per_split, int S, float *__restrict__ slab) {
+    __shared__ int list_sub[DW_LIST_CAP];
+    __shared__ int list_tile[DW_LIST_CAP];
+    __shared__ int scan_tmp[8];
+    __shared__ float red[4][CIN][64];
+    const int k = blockIdx.x, s = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int groups = 64 / COUT;          // rule slots handled per step by one wave
+    const int co = lane % COUT, grp = lane / COUT;
+    float acc[CIN];
+#pragma unroll
+    for (int c = 0; c < CIN; c++) acc[c] = 0.f;
+    const int t_begin = s * tiles_per_split;
+    const int t_end = min(n_tiles, t_begin + tiles_per_split);
+    for (int tb = t_begin; tb < t_end; tb += DW_TILES_PER_ITER) {
+        const int total = dw_build_list(tile_sub_start, seg_start, n_tiles, k, tb, t_end, list_sub, list_tile, scan_tmp);
+        for (int li = wave; li < total; li += 4) {
+            const int64_t c = list_sub[li];
+            const int64_t rowbase = (int64_t)list_tile[li] * TR;
+            for (int q = grp; q < SUB_SLOTS; q += groups) {
+                int src = sub_src[c * SUB_SLOTS + q];
+                if (src < 0) continue;
+                float dy = dY[(size_t)(rowbase + sub_dst[c * SUB_SLOTS + q]) * COUT + co];
+#pragma unroll
+                for (int ci = 0; ci < CIN; ci++) acc[ci] = fmaf(X[(size_t)src * CIN + ci], dy, acc[ci]);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int ci = 0; ci < CIN; ci++) red[wave][ci][lane] = acc[ci];
+    __syncthreads();
+    float *out = slab + (size_t)(k * S + s) * CIN * COUT;
+    for (int e = threadIdx.x; e < CIN * COUT; e += 256) {
+        int ci = e / COUT, c2 = e - ci * COUT;
+        float sum = 0.f;
+        for (int w = 0; w < 4; w++)
+            for (int gq = 0; gq < groups; gq++) sum += red[w][ci][gq * COUT + c2];
+        out[e] = sum;
+    }
+}
+
 // generic dW (any channel counts): one workgroup per (k, split); thread per (ci, co) element loop.
 __global__ __launch_bounds__(256) void conv_dw_generic_kernel(
-    const float *__restrict__ X, const float *__restrict__ dY, const int32_t *__restrict__ tile_chunk_start,
-    const int32_t *__restrict__ seg_start, const int32_t *__restrict__ chunk_src, const uint8_t *__restrict__ chunk_dst,
-    int n_tiles, int CIN, int COUT, int tiles_per_split, int S, float *__restrict__ slab) {
+    const float *__restrict__ X, const float *__restrict__ dY, const int32_t *__restrict__ tile_sub_start,
+    const int32_t *__restrict__ seg_start, const int32_t *__restrict__ sub_src, const uint8_t *__restrict__ sub_dst,
+    int n_tiles, int TR, int CIN, int COUT, int tiles_per_split, int S, float *__restrict__ slab) {
     const int k = blockIdx.x, s = blockIdx.y;
     const int t_begin = s * tiles_per_split;
     const int t_end = min(n_tiles, t_begin + tiles_per_split);
@@ -393,12 +536,12 @@ __global__ __launch_bounds__(256) void conv_dw_generic_kernel(
         int ci = e / COUT, co = e - ci * COUT;
         float sum = 0.f;
         for (int t = t_begin; t < t_end; t++) {
-            int64_t ca = tile_chunk_start[t] + seg_start[(size_t)k * n_tiles + t];
-            int64_t cb = tile_chunk_start[t] + seg_start[(size_t)(k + 1) * n_tiles + t];
-            for (int64_t sl = ca * CHUNK_SLOTS; sl < cb * CHUNK_SLOTS; sl++) {
-                int src = chunk_src[sl];
+            int64_t ca = tile_sub_start[t] + seg_start[(size_t)k * n_tiles + t];
+            int64_t cb = tile_sub_start[t] + seg_start[(size_t)(k + 1) * n_tiles + t];
+            for (int64_t sl = ca * SUB_SLOTS; sl < cb * SUB_SLOTS; sl++) {
+                int src = sub_src[sl];
                 if (src >= 0)
-                    sum = fmaf(X[(size_t)src * CIN + ci], dY[((size_t)t * TILE_ROWS + chunk_dst[sl]) * COUT + co], sum);
+                    sum = fmaf(X[(size_t)src * CIN + ci], dY[((size_t)t * TR + sub_dst[sl]) * COUT + co], sum);
             }
         }
         out[e] = sum;
@@ -426,8 +569,8 @@ static int launch_dw(const TiledRules &t, const float *X, const float *dY, int n
         attr_set = true;
     }
     dim3 grid(t.K, S, nIn / (16 * MT));
-    conv_dw_mfma_kernel<MT, NT><<<grid, 256, lds_bytes, st>>>(X, dY, t.tile_chunk_start, t.seg_start, t.chunk_src,
-                                                              t.chunk_dst, t.n_tiles, nIn, nOut, tps, S, slab);
+    conv_dw_mfma_kernel<MT, NT><<<grid, 256, lds_bytes, st>>>(X, dY, t.tile_sub_start, t.seg_start, t.sub_src, t.sub_dst,
+                                                              t.n_tiles, t.tile_rows, nIn, nOut, tps, S, slab);
     SEI_LAUNCH_CHECK();
     return 0;
 }
@@ -440,14 +583,15 @@ static int dispatch_dw(int mt, int nt, const TiledRules &t, const float *X, cons
     DW_CASE(1, 1) DW_CASE(1, 2) DW_CASE(1, 3) DW_CASE(1, 4) DW_CASE(1, 5) DW_CASE(1, 6) DW_CASE(1, 8) DW_CASE(1, 10) DW_CASE(1, 12)
     DW_CASE(2, 1) DW_CASE(2, 2) DW_CASE(2, 3) DW_CASE(2, 4) DW_CASE(2, 5) DW_CASE(2, 6) DW_CASE(2, 8) DW_CASE(2, 10) DW_CASE(2, 12)
     DW_CASE(3, 1) DW_CASE(3, 2) DW_CASE(3, 3) DW_CASE(3, 4) DW_CASE(3, 5) DW_CASE(3, 6) DW_CASE(3, 8) DW_CASE(3, 10) DW_CASE(3, 12)
-    DW_CASE(4, 1) DW_CASE(4, 2) DW_CASE(4, 3) DW_CASE(4, 4) DW_CASE(4, 5) DW_CASE(4, 6) DW_CASE(4, 8) DW_CASE(4, 10)
+    DW_CASE(4, 1) DW_CASE(4, 2) DW_CASE(4, 3) DW_CASE(4, 4) DW_CASE(4, 5) DW_CASE(4, 6) DW_CASE(4, 8) DW_CASE(4, 10) DW_CASE(4, 12)
+    DW_CASE(6, 6) DW_CASE(6, 8) DW_CASE(5, 10) DW_CASE(5, 12) DW_CASE(8, 8)
     SEI_FAIL("conv dW: no MFMA instantiation");
 }
 
 int conv_backward_weight(const TiledRules &t, const float *X, const float *dY, float *dW, int nIn, int nOut,
                          hipStream_t st) {
     const int64_t per = (int64_t)nIn * nOut;
-    if (t.n_chunks == 0 || t.n_dst == 0) {
+    if (t.n_sub == 0 || t.n_dst == 0) {
         SEI_HIP(hipMemsetAsync(dW, 0, (size_t)t.K * per * sizeof(float), st));
         return 0;
     }
@@ -457,15 +601,22 @@ int conv_backward_weight(const TiledRules &t, const float *X, const float *dY, f
     int mt = 0;
     if (mfma_ok) {
         int ct = nIn / 16;
-        for (int cand = 4; cand >= 1; cand--)
-            if (ct % cand == 0 && cand * nt <= 40) {
+        // widest ci block whose accumulators fit (<= 64 16x16 tiles = 256 registers)
+        const int cands[] = {8, 6, 5, 4, 3, 2, 1};
+        for (int cand : cands) {
+            bool inst = cand <= 4 ? (cand * nt <= 48) :
+                        ((cand == 6 && (nt == 6 || nt == 8)) || (cand == 5 && (nt == 10 || nt == 12)) ||
+                         (cand == 8 && nt == 8));
+            if (ct % cand == 0 && inst) {
                 mt = cand;
                 break;
             }
+        }
         if (!mt) mfma_ok = false;
     }
+    bool small = !mfma_ok && nIn <= 4 && (nOut == 16 || nOut == 32 || nOut == 64);
     // splits: enough workgroups to fill 256 CUs, bounded slab size
-    int S = (t.n_tiles + 255) / 256;
+    int S = (t.n_tiles + DW_TILES_PER_ITER - 1) / DW_TILES_PER_ITER;
     int target = (2048 + t.K - 1) / t.K;
     if (S > target) S = target;
     if (S > 64) S = 64;
@@ -474,19 +625,24 @@ int conv_backward_weight(const TiledRules &t, const float *X, const float *dY, f
     S = (t.n_tiles + tps - 1) / tps;
     float *slab;
     SEI_TRY(pool_alloc_t(&slab, (size_t)t.K * S * per));
-    int rc;
+    int rc = 0;
+    dim3 grid(t.K, S, 1);
     if (mfma_ok)
         rc = dispatch_dw(mt, nt, t, X, dY, nIn, nOut, tps, S, slab, st);
-    else {
-        dim3 grid(t.K, S, 1);
-        conv_dw_generic_kernel<<<grid, 256, 0, st>>>(X, dY, t.tile_chunk_start, t.seg_start, t.chunk_src, t.chunk_dst,
-                                                     t.n_tiles, nIn, nOut, tps, S, slab);
-        rc = 0;
+    else if (small) {
+#define SM(CIN_) conv_dw_smallcin_kernel<CIN_><<<grid, 256, 0, st>>>(X, dY, t.tile_sub_start, t.seg_start, t.sub_src, \
+                                                                      t.sub_dst, t.n_tiles, t.tile_rows, nOut, tps, S, slab)
+        if (nIn == 1) SM(1); else if (nIn == 2) SM(2); else if (nIn == 3) SM(3); else SM(4);
+#undef SM
+        if (hipGetLastError() != hipSuccess) rc = 1;
+    } else {
+        conv_dw_generic_kernel<<<grid, 256, 0, st>>>(X, dY, t.tile_sub_start, t.seg_start, t.sub_src, t.sub_dst,
+                                                     t.n_tiles, t.tile_rows, nIn, nOut, tps, S, slab);
         if (hipGetLastError() != hipSuccess) rc = 1;
     }
     if (rc) {
         pool_free(slab);
-        if (!mfma_ok) SEI_FAIL("conv dW generic launch failed");
+        if (!mfma_ok) SEI_FAIL("conv dW launch failed");
         return rc;
     }
     int64_t tot = (int64_t)t.K * per;

@@ -90,22 +90,30 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float *__restrict_
 //  0: BN stats -> save_mean, save_invstd, running update
 //  1: BN backward -> coef[0][C]=sum_dz/n, coef[1][C]=sum_dzxhat/n ; dgamma, dbeta
 //  2: colsum -> out[C]
-__global__ void finalize_kernel(const double *__restrict__ partial, int blocks, int C, int64_t n, int kind,
-                                float eps, float momentum, float *a0, float *a1, float *a2, float *a3) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+__global__ __launch_bounds__(64) void finalize_kernel(const double *__restrict__ partial, int blocks, int C, int64_t n,
+                                                      int kind, float eps, float momentum, float *a0, float *a1,
+                                                      float *a2, float *a3) {
+    // one wavefront per channel: lane l sums partials l, l+64, ... then a fixed-shape shuffle tree
+    const int c = blockIdx.x;
+    const int lane = threadIdx.x;
     double s0 = 0.0, s1 = 0.0;
-    for (int b = 0; b < blocks; b++) {
+    for (int b = lane; b < blocks; b += 64) {
         s0 += partial[(size_t)b * 2 * C + c];
         s1 += partial[(size_t)b * 2 * C + C + c];
     }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        s0 += __shfl_down(s0, d);
+        s1 += __shfl_down(s1, d);
+    }
+    if (lane != 0) return;
     if (kind == 0) {
         double mean = s0 / (double)n;
         double var = s1 / (double)n - mean * mean;
         if (var < 0.0) var = 0.0;
-        a0[c] = (float)mean;                          // save_mean
+        a0[c] = (float)mean;                             // save_mean
         a1[c] = (float)(1.0 / sqrt(var + (double)eps));  // save_invstd
-        if (a2) {                                     // running stats (SCN: r = m*r + (1-m)*batch, unbiased var)
+        if (a2) {                                        // running stats (SCN: r = m*r + (1-m)*batch, unbiased var)
             double unb = n > 1 ? var * (double)n / (double)(n - 1) : var;
             a2[c] = momentum * a2[c] + (1.f - momentum) * (float)mean;
             a3[c] = momentum * a3[c] + (1.f - momentum) * (float)unb;
@@ -152,7 +160,7 @@ int colsum(const float *x, int64_t n, int C, float *out, hipStream_t st) {
     double *partial;
     int blocks;
     SEI_TRY(reduce_launch(2, x, nullptr, nullptr, n, C, nullptr, nullptr, 1.f, &partial, &blocks, st));
-    finalize_kernel<<<(C + 63) / 64, 64, 0, st>>>(partial, blocks, C, n, 2, 0.f, 0.f, out, nullptr, nullptr, nullptr);
+    finalize_kernel<<<C, 64, 0, st>>>(partial, blocks, C, n, 2, 0.f, 0.f, out, nullptr, nullptr, nullptr);
     SEI_LAUNCH_CHECK();
     pool_free(partial);
     return 0;
@@ -259,7 +267,7 @@ int bn_forward(const float *x, int64_t n, int C, const float *gamma, const float
         double *partial;
         int blocks;
         SEI_TRY(reduce_launch(0, x, nullptr, nullptr, n, C, nullptr, nullptr, 1.f, &partial, &blocks, st));
-        finalize_kernel<<<(C + 63) / 64, 64, 0, st>>>(partial, blocks, C, n, 0, eps, momentum, save_mean, save_invstd,
+        finalize_kernel<<<C, 64, 0, st>>>(partial, blocks, C, n, 0, eps, momentum, save_mean, save_invstd,
                                                       rmean, rvar);
         SEI_LAUNCH_CHECK();
         pool_free(partial);
@@ -294,7 +302,7 @@ int bn_backward(const float *x, const float *y, const float *dy, int64_t n, int 
     double *partial;
     int blocks;
     SEI_TRY(reduce_launch(1, x, y, dy, n, C, save_mean, save_invstd, leak, &partial, &blocks, st));
-    finalize_kernel<<<(C + 63) / 64, 64, 0, st>>>(partial, blocks, C, n, 1, 0.f, 0.f, coef, coef + C, dgamma, dbeta);
+    finalize_kernel<<<C, 64, 0, st>>>(partial, blocks, C, n, 1, 0.f, 0.f, coef, coef + C, dgamma, dbeta);
     SEI_LAUNCH_CHECK();
     pool_free(partial);
     const float *cf = training ? coef : nullptr;

@@ -1,12 +1,10 @@
 // Rulebook construction on the device (SCN `getSubmanifoldRuleBook` / `getRuleBook`):
-// hash probes -> dense neighbour table -> per-wave-tile, per-offset compacted rule chunks.
-// Integer / HBM-MALL bound; the chunk layout is what the MFMA conv kernels consume
+// hash probes -> tile-blocked neighbour table -> per-tile, per-offset compacted sub-chunks of 16 rules.
+// Integer / HBM-MALL bound; the sub-chunk layout is what the MFMA conv kernels consume
 // ("per-wavefront rulebook segments").
 #include "common.h"
 
 namespace sei {
-
-int alloc_table(HashTable *ht, int64_t n, hipStream_t st);
 
 __device__ inline int hash_find(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, uint64_t mask,
                                 uint64_t key) {
@@ -19,160 +17,189 @@ __device__ inline int hash_find(const uint64_t *__restrict__ keys, const uint32_
     }
 }
 
-struct ProbeGeom {
-    int mode;  // 0 submanifold, 1 strided forward (dst = out sites), 2 strided transposed (dst = in sites)
-    int f0, f1, f2;     // filter size
-    int t0, t1, t2;     // stride
-    int s0, s1, s2;     // spatial size of the SRC level
-};
-
-// One thread per (dst row, offset k): nbr[row*K + k] = src row feeding dst row through offset k, or -1.
-__global__ void probe_kernel(const int32_t *__restrict__ dst_coords, int64_t n_dst, int K, ProbeGeom g,
-                             const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, uint64_t mask,
-                             int32_t *__restrict__ nbr) {
+// One thread per (tile, k, row-in-tile): nbr[(tile*K + k)*TR + r] = src row feeding dst row
+// tile*TR + r through offset k, or -1.  Consecutive lanes = consecutive dst rows, same offset:
+// coalesced coord reads / nbr writes, and the probed keys are spatial neighbours of each other.
+__global__ void probe_kernel(const int32_t *__restrict__ dst_coords, int64_t n_dst, int K, int TR, int n_tiles,
+                             ProbeGeom g, const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals,
+                             uint64_t mask, int32_t *__restrict__ nbr) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_dst * K) return;
-    int64_t row = t / K;
-    int k = (int)(t - row * K);
-    int4 c = reinterpret_cast<const int4 *>(dst_coords)[row];
-    int a = k / (g.f1 * g.f2), rem = k - a * (g.f1 * g.f2);
-    int b = rem / g.f2, d = rem - b * g.f2;
-    int q0, q1, q2;
-    bool ok = true;
-    if (g.mode == 0) {
-        q0 = c.x - g.f0 / 2 + a; q1 = c.y - g.f1 / 2 + b; q2 = c.z - g.f2 / 2 + d;
-    } else if (g.mode == 1) {
-        q0 = c.x * g.t0 + a; q1 = c.y * g.t1 + b; q2 = c.z * g.t2 + d;
-    } else {
-        int p0 = c.x - a, p1 = c.y - b, p2 = c.z - d;
-        ok = p0 >= 0 && p1 >= 0 && p2 >= 0 && (p0 % g.t0) == 0 && (p1 % g.t1) == 0 && (p2 % g.t2) == 0;
-        q0 = p0 / g.t0; q1 = p1 / g.t1; q2 = p2 / g.t2;
+    if (t >= (int64_t)n_tiles * K * TR) return;
+    int r = (int)(t % TR);
+    int64_t tk = t / TR;
+    int k = (int)(tk % K);
+    int64_t row = (tk / K) * TR + r;
+    int res = -1;
+    if (row < n_dst) {
+        int4 c = reinterpret_cast<const int4 *>(dst_coords)[row];
+        int a = k / (g.f1 * g.f2), rem = k - a * (g.f1 * g.f2);
+        int b = rem / g.f2, d = rem - b * g.f2;
+        int q0, q1, q2;
+        bool ok = true;
+        if (g.mode == 0) {
+            q0 = c.x - g.f0 / 2 + a; q1 = c.y - g.f1 / 2 + b; q2 = c.z - g.f2 / 2 + d;
+        } else if (g.mode == 1) {
+            q0 = c.x * g.t0 + a; q1 = c.y * g.t1 + b; q2 = c.z * g.t2 + d;
+        } else {
+            int p0 = c.x - a, p1 = c.y - b, p2 = c.z - d;
+            ok = p0 >= 0 && p1 >= 0 && p2 >= 0 && (p0 % g.t0) == 0 && (p1 % g.t1) == 0 && (p2 % g.t2) == 0;
+            q0 = p0 / g.t0; q1 = p1 / g.t1; q2 = p2 / g.t2;
+        }
+        ok = ok && q0 >= 0 && q0 < g.s0 && q1 >= 0 && q1 < g.s1 && q2 >= 0 && q2 < g.s2;
+        if (ok) res = hash_find(keys, vals, mask, pack_key(q0, q1, q2, c.w));
     }
-    ok = ok && q0 >= 0 && q0 < g.s0 && q1 >= 0 && q1 < g.s1 && q2 >= 0 && q2 < g.s2;
-    int r = -1;
-    if (ok) r = hash_find(keys, vals, mask, pack_key(q0, q1, q2, c.w));
-    nbr[t] = r;
+    nbr[t] = res;
 }
 
-// One wavefront per tile of 64 dst rows (lane = row).  Counts chunks per tile and records the
-// tile-relative chunk offset at which every filter offset k starts.
-__global__ void tile_count_kernel(const int32_t *__restrict__ nbr, int64_t n_dst, int K, int n_tiles,
-                                  int32_t *__restrict__ tile_chunks, int32_t *__restrict__ seg_start,
-                                  unsigned long long *__restrict__ totals /*[0]=rules [1]=subchunks*/) {
-    const int lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (tile >= n_tiles) return;
-    const int64_t row = (int64_t)tile * TILE_ROWS + lane;
-    int chunks = 0, rules = 0, subs = 0;
+// One workgroup (TR threads) per tile, thread = dst row.  FILL=false: count sub-chunks per offset and
+// record the tile-relative segment starts.  FILL=true: write the compacted, padded sub-chunks.
+template <bool FILL>
+__global__ void tile_rules_kernel(const int32_t *__restrict__ nbr, int K, int TR, int n_tiles,
+                                  int32_t *__restrict__ tile_subs, int32_t *__restrict__ tile_seg,
+                                  int32_t *__restrict__ seg_start, unsigned long long *__restrict__ totals,
+                                  const int32_t *__restrict__ tile_sub_start, int32_t *__restrict__ sub_src,
+                                  uint8_t *__restrict__ sub_dst) {
+    __shared__ int wcnt[2][4];
+    const int tile = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nw = TR >> 6;
+    const int32_t *nb = nbr + (int64_t)tile * K * TR;
+    int subs = 0, rules = 0;
+    int64_t base_sub = FILL ? tile_sub_start[tile] : 0;
     for (int k = 0; k < K; k++) {
-        bool hit = row < n_dst && nbr[row * K + k] >= 0;
-        int cnt = __popcll(__ballot(hit));
-        if (lane == 0) seg_start[(int64_t)k * n_tiles + tile] = chunks;
-        chunks += (cnt + CHUNK_SLOTS - 1) / CHUNK_SLOTS;
-        rules += cnt;
-        subs += (cnt + 15) / 16;
-    }
-    if (lane == 0) {
-        seg_start[(int64_t)K * n_tiles + tile] = chunks;
-        tile_chunks[tile] = chunks;
-        atomicAdd(&totals[0], (unsigned long long)rules);
-        atomicAdd(&totals[1], (unsigned long long)subs);
-    }
-}
-
-__global__ void tile_fill_kernel(const int32_t *__restrict__ nbr, int64_t n_dst, int K, int n_tiles,
-                                 const int32_t *__restrict__ tile_chunk_start, int32_t *__restrict__ chunk_src,
-                                 uint8_t *__restrict__ chunk_dst, uint8_t *__restrict__ chunk_k) {
-    const int lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (tile >= n_tiles) return;
-    const int64_t row = (int64_t)tile * TILE_ROWS + lane;
-    int64_t chunk = tile_chunk_start[tile];
-    for (int k = 0; k < K; k++) {
-        int src = row < n_dst ? nbr[row * K + k] : -1;
+        int src = nb[k * TR + threadIdx.x];
         bool hit = src >= 0;
         unsigned long long bal = __ballot(hit);
-        int cnt = __popcll(bal);
-        if (cnt == 0) continue;
-        int rank = __popcll(bal & ((1ull << lane) - 1ull));
-        int nch = (cnt + CHUNK_SLOTS - 1) / CHUNK_SLOTS;
-        int64_t base = chunk * CHUNK_SLOTS;
-        if (hit) {
-            chunk_src[base + rank] = src;
-            chunk_dst[base + rank] = (uint8_t)lane;
+        if (lane == 0) wcnt[k & 1][wave] = __popcll(bal);
+        __syncthreads();
+        int before = 0, cnt = 0;
+        for (int w = 0; w < nw; w++) {
+            int c = wcnt[k & 1][w];
+            if (w < wave) before += c;
+            cnt += c;
         }
-        // padding slots
-        int pad = nch * CHUNK_SLOTS - cnt;
-        if (lane < pad) {
-            chunk_src[base + cnt + lane] = -1;
-            chunk_dst[base + cnt + lane] = 0;
+        int ns = (cnt + SUB_SLOTS - 1) / SUB_SLOTS;
+        if (!FILL) {
+            if (threadIdx.x == 0) {
+                tile_seg[(int64_t)tile * (K + 1) + k] = subs;
+                seg_start[(int64_t)k * n_tiles + tile] = subs;
+            }
+        } else if (cnt > 0) {
+            int64_t slot0 = (base_sub + subs) * SUB_SLOTS;
+            if (hit) {
+                int rank = before + __popcll(bal & ((1ull << lane) - 1ull));
+                sub_src[slot0 + rank] = src;
+                sub_dst[slot0 + rank] = (uint8_t)threadIdx.x;
+            }
+            int pad = ns * SUB_SLOTS - cnt;
+            if ((int)threadIdx.x < pad) {
+                sub_src[slot0 + cnt + threadIdx.x] = -1;
+                sub_dst[slot0 + cnt + threadIdx.x] = 0;
+            }
         }
-        if (lane < nch) chunk_k[chunk + lane] = (uint8_t)k;
-        chunk += nch;
+        subs += ns;
+        rules += cnt;
+    }
+    if (!FILL && threadIdx.x == 0) {
+        tile_seg[(int64_t)tile * (K + 1) + K] = subs;
+        seg_start[(int64_t)K * n_tiles + tile] = subs;
+        tile_subs[tile] = subs;
+        atomicAdd(&totals[0], (unsigned long long)rules);
     }
 }
 
 void free_tiled(TiledRules &t) {
-    pool_free(t.tile_chunk_start); pool_free(t.chunk_src); pool_free(t.chunk_dst); pool_free(t.chunk_k);
-    pool_free(t.seg_start);
+    pool_free(t.tile_sub_start); pool_free(t.tile_seg); pool_free(t.seg_start); pool_free(t.sub_src);
+    pool_free(t.sub_dst);
     t = TiledRules();
 }
 
 // dst rows [n_dst] with coords dst_coords probe the src-level hash; result in *out.
 static int build_tiled(const int32_t *dst_coords, int64_t n_dst, int64_t n_src, const HashTable &src_ht, int K,
-                       ProbeGeom g, TiledRules *out, hipStream_t st) {
-    if (K > 255) SEI_FAIL("rulebook: filter volume > 255 not supported");
+                       ProbeGeom g, int tile_rows, TiledRules *out, hipStream_t st) {
+    if (K > 4096) SEI_FAIL("rulebook: filter volume too large");
     TiledRules t;
-    t.n_dst = n_dst; t.n_src = n_src; t.K = K;
-    t.n_tiles = (int)((n_dst + TILE_ROWS - 1) / TILE_ROWS);
-    SEI_TRY(pool_alloc_t(&t.tile_chunk_start, t.n_tiles + 1));
-    SEI_TRY(pool_alloc_t(&t.seg_start, (int64_t)(K + 1) * (t.n_tiles > 0 ? t.n_tiles : 1)));
+    t.n_dst = n_dst; t.n_src = n_src; t.K = K; t.tile_rows = tile_rows;
+    t.n_tiles = (int)((n_dst + tile_rows - 1) / tile_rows);
+    int nt1 = t.n_tiles > 0 ? t.n_tiles : 1;
+    SEI_TRY(pool_alloc_t(&t.tile_sub_start, nt1 + 1));
+    SEI_TRY(pool_alloc_t(&t.tile_seg, (int64_t)(K + 1) * nt1));
+    SEI_TRY(pool_alloc_t(&t.seg_start, (int64_t)(K + 1) * nt1));
     if (n_dst == 0) {
-        SEI_HIP(hipMemsetAsync(t.tile_chunk_start, 0, sizeof(int32_t), st));
-        SEI_TRY(pool_alloc_t(&t.chunk_src, 1)); SEI_TRY(pool_alloc_t(&t.chunk_dst, 1)); SEI_TRY(pool_alloc_t(&t.chunk_k, 1));
+        SEI_HIP(hipMemsetAsync(t.tile_sub_start, 0, 2 * sizeof(int32_t), st));
+        SEI_TRY(pool_alloc_t(&t.sub_src, 16)); SEI_TRY(pool_alloc_t(&t.sub_dst, 16));
+        t.built = true;
         *out = t;
         return 0;
     }
-    int32_t *nbr, *tile_chunks;
+    double bytes = 12.0 * n_dst + 8.0 * K * n_dst;
+    ProfScope ps(PROF_RULES, st, 0.0, bytes);
+    int32_t *nbr, *tile_subs;
     unsigned long long *totals;
-    SEI_TRY(pool_alloc_t(&nbr, n_dst * K));
-    SEI_TRY(pool_alloc_t(&tile_chunks, t.n_tiles + 1));
+    int64_t tot = (int64_t)t.n_tiles * K * tile_rows;
+    SEI_TRY(pool_alloc_t(&nbr, tot));
+    SEI_TRY(pool_alloc_t(&tile_subs, t.n_tiles + 1));
     SEI_TRY(pool_alloc_t(&totals, 4));
     SEI_HIP(hipMemsetAsync(totals, 0, 4 * sizeof(unsigned long long), st));
-    int64_t tot = n_dst * K;
-    probe_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, st>>>(dst_coords, n_dst, K, g, src_ht.keys, src_ht.vals,
-                                                               src_ht.mask, nbr);
-    const int WPB = 4;
-    int nb = (t.n_tiles + WPB - 1) / WPB;
-    tile_count_kernel<<<nb, WPB * 64, 0, st>>>(nbr, n_dst, K, t.n_tiles, tile_chunks, t.seg_start, totals);
+    probe_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, st>>>(dst_coords, n_dst, K, tile_rows, t.n_tiles, g,
+                                                               src_ht.keys, src_ht.vals, src_ht.mask, nbr);
+    tile_rules_kernel<false><<<t.n_tiles, tile_rows, 0, st>>>(nbr, K, tile_rows, t.n_tiles, tile_subs, t.tile_seg,
+                                                              t.seg_start, totals, nullptr, nullptr, nullptr);
     SEI_LAUNCH_CHECK();
-    SEI_TRY(exclusive_scan_i32(tile_chunks, t.tile_chunk_start, t.n_tiles, (int32_t *)(totals + 2), st));
-    // tile_chunk_start[n_tiles] = total
-    SEI_HIP(hipMemcpyAsync(t.tile_chunk_start + t.n_tiles, totals + 2, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    SEI_TRY(exclusive_scan_i32(tile_subs, t.tile_sub_start, t.n_tiles, (int32_t *)(totals + 2), st));
+    SEI_HIP(hipMemcpyAsync(t.tile_sub_start + t.n_tiles, totals + 2, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
     unsigned long long host[3];
     SEI_HIP(hipMemcpyAsync(host, totals, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     SEI_HIP(hipStreamSynchronize(st));
     t.n_rules = (int64_t)host[0];
-    t.n_sub = (int64_t)host[1];
-    t.n_chunks = (int64_t)(uint32_t)host[2];
-    int64_t nc = t.n_chunks > 0 ? t.n_chunks : 1;
-    SEI_TRY(pool_alloc_t(&t.chunk_src, nc * CHUNK_SLOTS));
-    SEI_TRY(pool_alloc_t(&t.chunk_dst, nc * CHUNK_SLOTS));
-    SEI_TRY(pool_alloc_t(&t.chunk_k, nc));
-    tile_fill_kernel<<<nb, WPB * 64, 0, st>>>(nbr, n_dst, K, t.n_tiles, t.tile_chunk_start, t.chunk_src, t.chunk_dst,
-                                              t.chunk_k);
+    t.n_sub = (int64_t)(uint32_t)host[2];
+    int64_t ns = t.n_sub > 0 ? t.n_sub : 1;
+    SEI_TRY(pool_alloc_t(&t.sub_src, ns * SUB_SLOTS));
+    SEI_TRY(pool_alloc_t(&t.sub_dst, ns * SUB_SLOTS));
+    tile_rules_kernel<true><<<t.n_tiles, tile_rows, 0, st>>>(nbr, K, tile_rows, t.n_tiles, nullptr, nullptr, nullptr,
+                                                             nullptr, t.tile_sub_start, t.sub_src, t.sub_dst);
     SEI_LAUNCH_CHECK();
-    pool_free(nbr); pool_free(tile_chunks); pool_free(totals);
+    pool_free(nbr); pool_free(tile_subs); pool_free(totals);
+    t.built = true;
     *out = t;
     return 0;
 }
 
-int build_subm_rules(Level *lv, const int32_t filter[3], TiledRules *out, hipStream_t st) {
-    int K = filter[0] * filter[1] * filter[2];
-    ProbeGeom g{0, filter[0], filter[1], filter[2], 1, 1, 1, lv->spatial[0], lv->spatial[1], lv->spatial[2]};
-    double bytes = 12.0 * lv->n + 8.0 * K * lv->n;
-    ProfScope ps(PROF_RULES, st, 0.0, bytes);
-    return build_tiled(lv->coords, lv->n, lv->n, lv->ht, K, g, out, st);
+int get_tiled(sei_rulebook *rb, bool transposed, int tile_rows, const TiledRules **out, hipStream_t st) {
+    if (tile_rows != 256 && tile_rows != 128) SEI_FAIL("rulebook: tile_rows must be 256 or 128");
+    std::lock_guard<std::mutex> lk(rb->mu);
+    if (rb->submanifold) transposed = false;
+    TiledRules &t = (transposed ? rb->bwd : rb->fwd)[variant_of(tile_rows)];
+    if (!t.built) {
+        int K = rb->size[0] * rb->size[1] * rb->size[2];
+        ProbeGeom g{rb->submanifold ? 0 : 1, rb->size[0], rb->size[1], rb->size[2], rb->stride[0], rb->stride[1],
+                    rb->stride[2], rb->lin->spatial[0], rb->lin->spatial[1], rb->lin->spatial[2]};
+        if (!transposed) {
+            // dst = output sites probing the input-level hash
+            SEI_TRY(build_tiled(rb->lout->coords, rb->lout->n, rb->lin->n, rb->lin->ht, K, g, tile_rows, &t, st));
+        } else {
+            // dst = input sites probing the output-level hash
+            g.mode = 2;
+            g.s0 = rb->lout->spatial[0]; g.s1 = rb->lout->spatial[1]; g.s2 = rb->lout->spatial[2];
+            SEI_TRY(build_tiled(rb->lin->coords, rb->lin->n, rb->lout->n, rb->lout->ht, K, g, tile_rows, &t, st));
+        }
+    }
+    *out = &t;
+    return 0;
+}
+
+int get_any_tiled(sei_rulebook *rb, bool transposed, const TiledRules **out, hipStream_t st) {
+    {
+        std::lock_guard<std::mutex> lk(rb->mu);
+        if (rb->submanifold) transposed = false;
+        TiledRules *v = transposed ? rb->bwd : rb->fwd;
+        for (int i = 0; i < SEI_NVARIANT; i++)
+            if (v[i].built) {
+                *out = &v[i];
+                return 0;
+            }
+    }
+    return get_tiled(rb, transposed, 256, out, st);
 }
 
 // ------------------------------------------------------------------ strided conv: output-site discovery
@@ -248,8 +275,9 @@ Level *find_level(sei_metadata *m, const int32_t spatial[3]) {
     return nullptr;
 }
 
-int build_strided(sei_metadata *m, Level *lin, const int32_t size[3], const int32_t stride[3], int32_t batch,
-                  sei_rulebook *rb, hipStream_t st) {
+// Discovers the output active set of a strided convolution and registers it as a new level.
+int build_strided_level(sei_metadata *m, Level *lin, const int32_t size[3], const int32_t stride[3], sei_rulebook *rb,
+                        hipStream_t st) {
     int32_t osz[3];
     for (int d = 0; d < 3; d++) {
         if (size[d] < 1 || stride[d] < 1) SEI_FAIL("Convolution: bad filter size / stride");
@@ -258,15 +286,13 @@ int build_strided(sei_metadata *m, Level *lin, const int32_t size[3], const int3
         rb->spatial_out[d] = osz[d];
     }
     if (find_level(m, osz)) SEI_FAIL("Convolution: a level with the output spatial size already exists in this metadata");
-    int K = size[0] * size[1] * size[2];
     int m0 = (size[0] + stride[0] - 1) / stride[0], m1 = (size[1] + stride[1] - 1) / stride[1],
         m2 = (size[2] + stride[2] - 1) / stride[2];
     int mult = m0 * m1 * m2;
     int64_t n = lin->n;
     ProbeGeom g{1, size[0], size[1], size[2], stride[0], stride[1], stride[2], lin->spatial[0], lin->spatial[1],
                 lin->spatial[2]};
-    double bytes = 12.0 * n * mult + 8.0 * K * n;
-    ProfScope ps(PROF_RULES, st, 0.0, bytes);
+    ProfScope ps(PROF_RULES, st, 0.0, 12.0 * n * mult);
     Level *lo = new Level();
     for (int d = 0; d < 3; d++) lo->spatial[d] = osz[d];
     int64_t cand = n * mult;
@@ -302,41 +328,39 @@ int build_strided(sei_metadata *m, Level *lin, const int32_t size[3], const int3
         pool_free(slot_of); pool_free(flag); pool_free(total);
     }
     m->levels.push_back(lo);
-    // forward rules: dst = output sites probing the input hash
-    SEI_TRY(build_tiled(lo->coords, lo->n, lin->n, lin->ht, K, g, &rb->fwd, st));
-    // transposed rules: dst = input sites probing the output hash
-    ProbeGeom gt = g;
-    gt.mode = 2;
-    gt.s0 = osz[0]; gt.s1 = osz[1]; gt.s2 = osz[2];
-    SEI_TRY(build_tiled(lin->coords, lin->n, lo->n, lo->ht, K, gt, &rb->bwd, st));
+    rb->lin = lin;
+    rb->lout = lo;
     return 0;
 }
 
 // ------------------------------------------------------------------ export as k-major lists (tests / inspection)
-__global__ void export_count_kernel(const int32_t *chunk_src, const uint8_t *chunk_k, int64_t n_chunks,
-                                    unsigned long long *per_k) {
-    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n_chunks) return;
+__global__ void export_count_kernel(const int32_t *tile_sub_start, const int32_t *seg_start, int n_tiles, int K,
+                                    const int32_t *sub_src, unsigned long long *per_k) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)K * n_tiles) return;
+    int k = (int)(idx / n_tiles), t = (int)(idx - (int64_t)k * n_tiles);
+    int64_t c0 = tile_sub_start[t] + seg_start[(int64_t)k * n_tiles + t];
+    int64_t c1 = tile_sub_start[t] + seg_start[(int64_t)(k + 1) * n_tiles + t];
     int cnt = 0;
-    for (int s = 0; s < CHUNK_SLOTS; s++) cnt += chunk_src[c * CHUNK_SLOTS + s] >= 0;
-    atomicAdd(&per_k[chunk_k[c]], (unsigned long long)cnt);
+    for (int64_t s = c0 * SUB_SLOTS; s < c1 * SUB_SLOTS; s++) cnt += sub_src[s] >= 0;
+    if (cnt) atomicAdd(&per_k[k], (unsigned long long)cnt);
 }
 
 // single-thread-per-k sequential fill keeps (tile, slot) order: deterministic, test-only path.
-__global__ void export_fill_kernel(const int32_t *tile_chunk_start, const int32_t *seg_start, int n_tiles, int K,
-                                   const int32_t *chunk_src, const uint8_t *chunk_dst,
-                                   const unsigned long long *start, int32_t *rin, int32_t *rout) {
+__global__ void export_fill_kernel(const int32_t *tile_sub_start, const int32_t *seg_start, int n_tiles, int K, int TR,
+                                   const int32_t *sub_src, const uint8_t *sub_dst, const unsigned long long *start,
+                                   int32_t *rin, int32_t *rout) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= K) return;
     int64_t pos = (int64_t)start[k];
     for (int t = 0; t < n_tiles; t++) {
-        int64_t c0 = tile_chunk_start[t] + seg_start[(int64_t)k * n_tiles + t];
-        int64_t c1 = tile_chunk_start[t] + seg_start[(int64_t)(k + 1) * n_tiles + t];
-        for (int64_t s = c0 * CHUNK_SLOTS; s < c1 * CHUNK_SLOTS; s++) {
-            int src = chunk_src[s];
+        int64_t c0 = tile_sub_start[t] + seg_start[(int64_t)k * n_tiles + t];
+        int64_t c1 = tile_sub_start[t] + seg_start[(int64_t)(k + 1) * n_tiles + t];
+        for (int64_t s = c0 * SUB_SLOTS; s < c1 * SUB_SLOTS; s++) {
+            int src = sub_src[s];
             if (src >= 0) {
                 rin[pos] = src;
-                rout[pos] = t * TILE_ROWS + chunk_dst[s];
+                rout[pos] = t * TR + sub_dst[s];
                 pos++;
             }
         }
@@ -347,8 +371,10 @@ int export_rules(const TiledRules &t, int64_t *start_host, int32_t *rin, int32_t
     unsigned long long *per_k;
     SEI_TRY(pool_alloc_t(&per_k, 2 * (t.K + 1)));
     SEI_HIP(hipMemsetAsync(per_k, 0, 2 * (t.K + 1) * sizeof(unsigned long long), st));
-    if (t.n_chunks > 0)
-        export_count_kernel<<<(unsigned)((t.n_chunks + 255) / 256), 256, 0, st>>>(t.chunk_src, t.chunk_k, t.n_chunks, per_k);
+    int64_t tot = (int64_t)t.K * t.n_tiles;
+    if (t.n_sub > 0)
+        export_count_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, st>>>(t.tile_sub_start, t.seg_start, t.n_tiles, t.K,
+                                                                          t.sub_src, per_k);
     std::vector<unsigned long long> h(t.K + 1);
     SEI_HIP(hipMemcpyAsync(h.data(), per_k, t.K * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     SEI_HIP(hipStreamSynchronize(st));
@@ -357,9 +383,9 @@ int export_rules(const TiledRules &t, int64_t *start_host, int32_t *rin, int32_t
     for (int k = 0; k < t.K; k++) start[k + 1] = start[k] + h[k];
     for (int k = 0; k <= t.K; k++) start_host[k] = (int64_t)start[k];
     SEI_HIP(hipMemcpyAsync(per_k + t.K + 1, start.data(), (t.K + 1) * sizeof(unsigned long long), hipMemcpyHostToDevice, st));
-    if (t.n_chunks > 0 && rin && rout)
-        export_fill_kernel<<<(t.K + 63) / 64, 64, 0, st>>>(t.tile_chunk_start, t.seg_start, t.n_tiles, t.K, t.chunk_src,
-                                                          t.chunk_dst, per_k + t.K + 1, rin, rout);
+    if (t.n_sub > 0 && rin && rout)
+        export_fill_kernel<<<(t.K + 63) / 64, 64, 0, st>>>(t.tile_sub_start, t.seg_start, t.n_tiles, t.K, t.tile_rows,
+                                                          t.sub_src, t.sub_dst, per_k + t.K + 1, rin, rout);
     SEI_LAUNCH_CHECK();
     SEI_HIP(hipStreamSynchronize(st));
     pool_free(per_k);

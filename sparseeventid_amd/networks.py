@@ -194,7 +194,20 @@ class multi_head_output(nn.Module):
             {key: create_final_dense_chain(spatial_shape, n_in, output_shape[key]) for key in output_shape.keys()})
 
     def forward(self, x):
-        return {key: self.classification_head[key](x) for key in self.classification_head.keys()}
+        heads = self.classification_head
+        first = [heads[k][0] for k in heads.keys()]
+        if x.dim() == 5 and all(isinstance(p, nn.AvgPool3d) and _full_window(p, x) for p in first):
+            # every head opens with the same global AvgPool3d: pool the dense tensor ONCE (a full-window
+            # average is the mean over the spatial dims) and hand it to the rest of each chain.
+            pooled = x.mean(dim=(2, 3, 4), keepdim=True)
+            return {key: heads[key][1:](pooled) for key in heads.keys()}
+        return {key: heads[key](x) for key in heads.keys()}
+
+
+def _full_window(pool, x):
+    ks = pool.kernel_size
+    ks = (ks, ks, ks) if isinstance(ks, int) else tuple(ks)
+    return tuple(int(k) for k in ks) == tuple(x.shape[2:]) and pool.padding in (0, (0, 0, 0))
 
 
 def build_networks(params, input_shape, output_shape):

@@ -116,9 +116,9 @@ class Rulebook:
         self.metadata = metadata
         self.h = handle
         self.spatial_out = spatial_out
-        info = (ctypes.c_int64 * 6)()
+        info = (ctypes.c_int64 * 8)()
         check(lib().sei_rulebook_info(handle, info))
-        self.n_dst, self.n_src, self.K, self.n_rules, self.n_chunks, self.n_tiles = [int(x) for x in info]
+        self.n_dst, self.n_src, self.K, self.n_rules, self.n_sub, self.n_tiles, _, self.tile_rows = [int(x) for x in info]
 
     def export(self, device):
         start = (ctypes.c_int64 * (self.K + 1))()
