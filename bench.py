@@ -95,7 +95,8 @@ def main():
 
     # synthetic input is generated BEFORE the GPU is touched (fork pool)
     ncpu = os.cpu_count() or 8
-    workers = max(1, min(16, ncpu // max(world, 1)))
+    workers = int(os.environ.get("SEI_GEN_WORKERS", "0")) or max(1, min(16, ncpu // max(world, 1)))
+    # (under `rocprofv3 --pmc` the GPU is initialised before python starts: set SEI_GEN_WORKERS=1, no fork)
     grid = tuple(args.grid)
     arr, labels = generate_batch(rank, 0, args.batch, grid, args.voxels, args.kind, workers)
 

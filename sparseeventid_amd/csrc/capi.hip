@@ -243,7 +243,7 @@ int sei_subm_rulebook(sei_metadata_t *m, const int32_t spatial[3], const int32_t
     }
     rb->lin = rb->lout = l;
     const TiledRules *t;
-    int rc = get_tiled(rb, false, 256, &t, (hipStream_t)stream);
+    int rc = get_tiled(rb, false, 128, &t, (hipStream_t)stream);
     if (rc) {
         delete rb;
         return rc;
@@ -273,7 +273,7 @@ int sei_conv_rulebook(sei_metadata_t *m, const int32_t spatial_in[3], const int3
     }
     int rc = build_strided_level(m, l, size, stride, rb, (hipStream_t)stream);
     const TiledRules *t;
-    if (!rc) rc = get_tiled(rb, false, 256, &t, (hipStream_t)stream);
+    if (!rc) rc = get_tiled(rb, false, 128, &t, (hipStream_t)stream);
     if (rc) {
         delete rb;
         return rc;

@@ -111,7 +111,7 @@ struct ProbeGeom {
 
 }  // namespace sei
 
-constexpr int SEI_NVARIANT = 2;  // tile_rows 256 / 128
+constexpr int SEI_NVARIANT = 3;  // tile_rows 256 / 128 / 64
 struct sei_rulebook {
     sei::TiledRules fwd[SEI_NVARIANT];  // dst = output rows, src = input rows
     sei::TiledRules bwd[SEI_NVARIANT];  // dst = input rows,  src = output rows (strided conv only)
@@ -146,7 +146,7 @@ int input_features_fwd(sei_metadata *m, const float *in, int C, float *out, hipS
 int input_features_bwd(sei_metadata *m, const float *dout, int C, float *din, hipStream_t st);
 int exclusive_scan_i32(const int32_t *in, int32_t *out, int64_t n, int32_t *total_dev, hipStream_t st);
 // rulebook.hip
-inline int variant_of(int tile_rows) { return tile_rows == 256 ? 0 : 1; }
+inline int variant_of(int tile_rows) { return tile_rows == 256 ? 0 : (tile_rows == 128 ? 1 : 2); }
 // returns the (lazily built) tiled rules of the rulebook: transposed=false -> fwd, true -> bwd
 int get_tiled(sei_rulebook *rb, bool transposed, int tile_rows, const TiledRules **out, hipStream_t st);
 // any already-built variant (prefers 256 rows), building the 256 one if none exists

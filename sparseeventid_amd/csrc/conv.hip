@@ -25,329 +25,6 @@ __device__ inline void lds_add(float *p, float v) {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-__device__ inline float4 load_a(const float *__restrict__ X, int src, int CIN, int off) {
-    if (src >= 0) return *reinterpret_cast<const float4 *>(X + (size_t)src * CIN + off);
-    return make_float4(0.f, 0.f, 0.f, 0.f);
-}
-
-constexpr int MAXS = 4;  // sub-chunks of one offset a wave can own: tile_rows / 16 / units
-
-// NT  = 16-column tiles per wave, CS = waves sharing one sub-chunk (column split), SLJ = slice / 16.
-// tile_rows = 256 / CS.  LDS: acc[tile_rows][COUT] | wbuf[2][SL][COUT] | seg[K+1]
-template <int NT, int CS, int SLJ>
-__global__ __launch_bounds__(256) void conv_tile_mfma_kernel(
-    const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ Y,
-    const int32_t *__restrict__ tile_sub_start, const int32_t *__restrict__ tile_seg,
-    const int32_t *__restrict__ sub_src, const uint8_t *__restrict__ sub_dst, int64_t n_dst, int K, int CIN, int COUT) {
-    extern __shared__ float lds[];
-    constexpr int TR = 256 / CS;
-    constexpr int U = 4 / CS;  // units (groups of CS waves) dealing sub-chunks
-    constexpr int SL = 16 * SLJ;
-    constexpr int NC = NT * 16;
-    const int tile = blockIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int unit = wave / CS, cg = wave - unit * CS;
-    const int col0 = cg * NC;
-    const int r16 = lane & 15, g = lane >> 4;
-    float *acc_tile = lds;
-    float *wbuf = lds + (size_t)TR * COUT;
-    int *seg = reinterpret_cast<int *>(wbuf + 2 * SL * COUT);
-
-    for (int i = threadIdx.x; i <= K; i += 256) seg[i] = tile_seg[(size_t)tile * (K + 1) + i];
-    {
-        const int V = COUT >> 2;
-        for (int idx = threadIdx.x; idx < TR * V; idx += 256) {
-            int v = idx % V;
-            float4 b = bias ? *reinterpret_cast<const float4 *>(bias + 4 * v) : make_float4(0.f, 0.f, 0.f, 0.f);
-            *reinterpret_cast<float4 *>(acc_tile + (size_t)idx * 4) = b;
-        }
-    }
-    __syncthreads();
-
-    const int64_t sub0 = tile_sub_start[tile];
-    const int NS = CIN / SL;              // slices per offset
-    const int slice_f4 = SL * COUT / 4;   // float4 per slice (contiguous in W)
-    // staging registers: each thread copies up to 3 float4 of a slice (SL*COUT/4 <= 768*... checked on host)
-    constexpr int STG = 3 * SLJ > 6 ? 6 : 3 * SLJ;
-    float4 wreg[STG];
-
-    auto stage_issue = [&](int k, int s) {
-        const float4 *src = reinterpret_cast<const float4 *>(W + ((size_t)k * CIN + (size_t)s * SL) * COUT);
-#pragma unroll
-        for (int q = 0; q < STG; q++) {
-            int i = threadIdx.x + q * 256;
-            if (i < slice_f4) wreg[q] = src[i];
-        }
-    };
-    auto stage_commit = [&](int buf) {
-        float4 *dst = reinterpret_cast<float4 *>(wbuf + (size_t)buf * SL * COUT);
-#pragma unroll
-        for (int q = 0; q < STG; q++) {
-            int i = threadIdx.x + q * 256;
-            if (i < slice_f4) dst[i] = wreg[q];
-        }
-    };
-    auto next_k = [&](int k) {
-        k++;
-        while (k < K && seg[k + 1] == seg[k]) k++;
-        return __builtin_amdgcn_readfirstlane(k);
-    };
-
-    int src_c[MAXS], dst_c[MAXS], src_n[MAXS], dst_n[MAXS];
-    int ms_c = 0, ms_n = 0;
-    auto load_idx = [&](int k, int *srcs, int *dsts) {
-        int s0 = __builtin_amdgcn_readfirstlane(seg[k]), ns = __builtin_amdgcn_readfirstlane(seg[k + 1]) - s0;
-        int ms = 0;
-#pragma unroll
-        for (int m = 0; m < MAXS; m++) {
-            int s = unit + m * U;
-            if (s < ns) {
-                int64_t slot = (sub0 + s0 + s) * SUB_SLOTS + r16;
-                srcs[m] = sub_src[slot];
-                dsts[m] = sub_dst[slot];
-                ms = m + 1;
-            } else {
-                srcs[m] = -1;
-                dsts[m] = 0;
-            }
-        }
-        return __builtin_amdgcn_readfirstlane(ms);
-    };
-
-    int k = next_k(-1);
-    if (k < K) {
-        ms_c = load_idx(k, src_c, dst_c);
-        stage_issue(k, 0);
-        float4 a_c[MAXS][SLJ], a_n[MAXS][SLJ];
-#pragma unroll
-        for (int m = 0; m < MAXS; m++)
-#pragma unroll
-            for (int jj = 0; jj < SLJ; jj++) a_n[m][jj] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int m = 0; m < MAXS; m++)
-#pragma unroll
-            for (int jj = 0; jj < SLJ; jj++) a_c[m][jj] = load_a(X, src_c[m], CIN, 16 * jj + 4 * g);
-        int phase = 0;
-        while (k < K) {
-            const int kn = next_k(k);
-            if (kn < K) ms_n = load_idx(kn, src_n, dst_n);
-            f32x4 acc[MAXS][NT];
-#pragma unroll
-            for (int m = 0; m < MAXS; m++)
-#pragma unroll
-                for (int n = 0; n < NT; n++) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            for (int s = 0; s < NS; s++) {
-                stage_commit(phase & 1);
-                __syncthreads();
-                // prefetch the next phase's weight slice and A fragments while this one computes
-                if (s + 1 < NS) {
-                    stage_issue(k, s + 1);
-#pragma unroll
-                    for (int m = 0; m < MAXS; m++)
-#pragma unroll
-                        for (int jj = 0; jj < SLJ; jj++)
-                            a_n[m][jj] = load_a(X, src_c[m], CIN, (s + 1) * SL + 16 * jj + 4 * g);
-                } else if (kn < K) {
-                    stage_issue(kn, 0);
-#pragma unroll
-                    for (int m = 0; m < MAXS; m++)
-#pragma unroll
-                        for (int jj = 0; jj < SLJ; jj++) a_n[m][jj] = load_a(X, src_n[m], CIN, 16 * jj + 4 * g);
-                }
-                const float *wb = wbuf + (size_t)(phase & 1) * SL * COUT + col0 + r16;
-#pragma unroll
-                for (int jj = 0; jj < SLJ; jj++) {
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        float b[NT];
-#pragma unroll
-                        for (int n = 0; n < NT; n++) b[n] = wb[(16 * jj + 4 * g + e) * COUT + 16 * n];
-#pragma unroll
-                        for (int m = 0; m < MAXS; m++) {
-                            if (m < ms_c) {
-                                const float av = e == 0 ? a_c[m][jj].x : e == 1 ? a_c[m][jj].y : e == 2 ? a_c[m][jj].z : a_c[m][jj].w;
-#pragma unroll
-                                for (int n = 0; n < NT; n++) acc[m][n] = mfma16(av, b[n], acc[m][n]);
-                            }
-                        }
-                    }
-                }
-#pragma unroll
-                for (int m = 0; m < MAXS; m++)
-#pragma unroll
-                    for (int jj = 0; jj < SLJ; jj++) a_c[m][jj] = a_n[m][jj];
-                phase++;
-            }
-            // D[row = 4g+i][col = r16] belongs to rule slot 4g+i of the sub-chunk
-#pragma unroll
-            for (int m = 0; m < MAXS; m++) {
-                if (m < ms_c) {
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        int sr = __shfl(src_c[m], 4 * g + i), dd = __shfl(dst_c[m], 4 * g + i);
-                        if (sr >= 0) {
-                            float *p = acc_tile + dd * COUT + col0 + r16;
-#pragma unroll
-                            for (int n = 0; n < NT; n++) lds_add(p + 16 * n, acc[m][n][i]);
-                        }
-                    }
-                }
-            }
-#pragma unroll
-            for (int m = 0; m < MAXS; m++) {
-                src_c[m] = src_n[m];
-                dst_c[m] = dst_n[m];
-            }
-            ms_c = ms_n;
-            k = kn;
-        }
-    }
-    __syncthreads();
-    // epilogue: every dst row is written once, as whole float4 row segments
-    const int V = COUT >> 2;
-    const int64_t row0 = (int64_t)tile * TR;
-    for (int idx = threadIdx.x; idx < TR * V; idx += 256) {
-        int r = idx / V;
-        if (row0 + r < n_dst)
-            *reinterpret_cast<float4 *>(Y + (size_t)row0 * COUT + (size_t)idx * 4) =
-                *reinterpret_cast<const float4 *>(acc_tile + (size_t)idx * 4);
-    }
-}
-
-// Any channel counts (stem Cin=1, odd test sizes): same tile / sub-chunk walk, scalar FMA.
-__global__ __launch_bounds__(256) void conv_tile_generic_kernel(
-    const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ Y,
-    const int32_t *__restrict__ tile_sub_start, const int32_t *__restrict__ tile_seg,
-    const int32_t *__restrict__ sub_src, const uint8_t *__restrict__ sub_dst, int64_t n_dst, int K, int CIN, int COUT,
-    int TR) {
-    extern __shared__ float lds[];
-    const int tile = blockIdx.x;
-    float *acc = lds;
-    for (int idx = threadIdx.x; idx < TR * COUT; idx += 256) acc[idx] = bias ? bias[idx % COUT] : 0.f;
-    __syncthreads();
-    const int64_t sub0 = tile_sub_start[tile];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r16 = lane & 15, g = lane >> 4;
-    for (int k = 0; k < K; k++) {
-        const int s0 = tile_seg[(size_t)tile * (K + 1) + k], s1 = tile_seg[(size_t)tile * (K + 1) + k + 1];
-        const float *Wk = W + (size_t)k * CIN * COUT;
-        for (int s = s0 + wave; s < s1; s += 4) {
-            int64_t slot = (sub0 + s) * SUB_SLOTS + r16;
-            int src = sub_src[slot], d = sub_dst[slot];
-            if (src < 0) continue;
-            const float *xr = X + (size_t)src * CIN;
-            for (int co = g; co < COUT; co += 4) {
-                float sum = 0.f;
-                for (int ci = 0; ci < CIN; ci++) sum = fmaf(xr[ci], Wk[(size_t)ci * COUT + co], sum);
-                lds_add(&acc[d * COUT + co], sum);
-            }
-        }
-        __syncthreads();  // keeps the per-row sum order fixed (k-phases), as in the MFMA kernel
-    }
-    const int64_t row0 = (int64_t)tile * TR;
-    for (int idx = threadIdx.x; idx < TR * COUT; idx += 256) {
-        int r = idx / COUT;
-        if (row0 + r < n_dst) Y[(size_t)row0 * COUT + idx] = acc[idx];
-    }
-}
-
-__global__ void fill_bias_kernel(float *Y, int64_t n, int C, const float *bias) {
-    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n * C) Y[t] = bias ? bias[t % C] : 0.f;
-}
-
-struct FwdPlan {
-    bool mfma;
-    int nt, cs, slj, tile_rows;
-    size_t lds_bytes;
-};
-
-static size_t fwd_lds(int tile_rows, int nOut, int slj, int K) {
-    return ((size_t)tile_rows * nOut + 2 * 16 * slj * nOut) * sizeof(float) + (K + 1) * sizeof(int);
-}
-
-static FwdPlan plan_forward(int nIn, int nOut, int K) {
-    FwdPlan p{};
-    p.mfma = (nIn % 16 == 0) && (nOut % 16 == 0) && nIn >= 16;
-    p.cs = 1;
-    p.nt = nOut / 16;
-    if (p.mfma && p.nt > 6) {
-        if (nOut % 32 == 0 && nOut / 32 <= 6) {
-            p.cs = 2;
-            p.nt = nOut / 32;
-        } else
-            p.mfma = false;
-    }
-    if (p.mfma) {
-        // the tile size may depend on nOut only (the rulebook variant is chosen from it): decide the
-        // column split with the worst-case slice (32 planes) and filter volume (125)
-        if (fwd_lds(256 / p.cs, nOut, 2, 125) > 160 * 1024 && p.cs == 1 && nOut % 32 == 0) {
-            p.cs = 2;
-            p.nt = nOut / 32;
-        }
-        p.tile_rows = 256 / p.cs;
-        p.slj = (nIn % 32 == 0) ? 2 : 1;
-        p.lds_bytes = fwd_lds(p.tile_rows, nOut, p.slj, K);
-        if (p.lds_bytes > 160 * 1024) p.mfma = false;
-    }
-    if (!p.mfma) {
-        p.tile_rows = (size_t)256 * nOut * sizeof(float) <= 96 * 1024 ? 256 : 128;
-        p.lds_bytes = (size_t)p.tile_rows * nOut * sizeof(float);
-    }
-    return p;
-}
-
-int conv_tile_rows(int nIn, int nOut) { return plan_forward(nIn, nOut, 27).tile_rows; }
-
-template <int NT, int CS, int SLJ>
-static int launch_mfma(const TiledRules &t, const FwdPlan &p, const float *X, const float *W, const float *bias,
-                       float *Y, int nIn, int nOut, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        SEI_HIP(hipFuncSetAttribute((const void *)conv_tile_mfma_kernel<NT, CS, SLJ>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
-    conv_tile_mfma_kernel<NT, CS, SLJ><<<t.n_tiles, 256, p.lds_bytes, st>>>(
-        X, W, bias, Y, t.tile_sub_start, t.tile_seg, t.sub_src, t.sub_dst, t.n_dst, t.K, nIn, nOut);
-    SEI_LAUNCH_CHECK();
-    return 0;
-}
-
-#define FWD_CASE(NT_, CS_, SLJ_) \
-    if (p.nt == NT_ && p.cs == CS_ && p.slj == SLJ_) return launch_mfma<NT_, CS_, SLJ_>(t, p, X, W, bias, Y, nIn, nOut, st);
-
-int conv_forward(const TiledRules &t, const float *X, const float *W, const float *bias, float *Y, int nIn, int nOut,
-                 hipStream_t st) {
-    if (t.n_dst == 0) return 0;
-    if (t.n_sub == 0) {
-        int64_t tot = t.n_dst * nOut;
-        fill_bias_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, st>>>(Y, t.n_dst, nOut, bias);
-        SEI_LAUNCH_CHECK();
-        return 0;
-    }
-    FwdPlan p = plan_forward(nIn, nOut, t.K);
-    if (p.tile_rows != t.tile_rows) SEI_FAIL("conv_forward: rulebook tile size does not match the kernel plan");
-    if (p.mfma) {
-        FWD_CASE(1, 1, 1) FWD_CASE(2, 1, 1) FWD_CASE(3, 1, 1) FWD_CASE(4, 1, 1) FWD_CASE(5, 1, 1) FWD_CASE(6, 1, 1)
-        FWD_CASE(1, 1, 2) FWD_CASE(2, 1, 2) FWD_CASE(3, 1, 2) FWD_CASE(4, 1, 2) FWD_CASE(5, 1, 2) FWD_CASE(6, 1, 2)
-        FWD_CASE(4, 2, 1) FWD_CASE(5, 2, 1) FWD_CASE(6, 2, 1) FWD_CASE(3, 2, 1)
-        FWD_CASE(4, 2, 2) FWD_CASE(5, 2, 2) FWD_CASE(6, 2, 2) FWD_CASE(3, 2, 2)
-        SEI_FAIL("conv_forward: no MFMA instantiation for this plan");
-    }
-    if (p.lds_bytes > 160 * 1024) SEI_FAIL("conv: nOut too large for the generic kernel");
-    static bool attr_set = false;
-    if (!attr_set) {
-        SEI_HIP(hipFuncSetAttribute((const void *)conv_tile_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    160 * 1024));
-        attr_set = true;
-    }
-    conv_tile_generic_kernel<<<t.n_tiles, 256, p.lds_bytes, st>>>(X, W, bias, Y, t.tile_sub_start, t.tile_seg, t.sub_src,
-                                                                 t.sub_dst, t.n_dst, t.K, nIn, nOut, t.tile_rows);
-    SEI_LAUNCH_CHECK();
-    return 0;
-}
-
 // Wt[k][co][ci] = W[flip ? K-1-k : k][ci][co]
 __global__ void transform_weights_kernel(const float *__restrict__ W, float *__restrict__ Wt, int K, int nIn, int nOut,
                                          int flip) {

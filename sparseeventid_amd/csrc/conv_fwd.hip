@@ -1,0 +1,411 @@
+// Sparse convolution forward / dX for gfx950 (scn.SubmanifoldConvolution / scn.Convolution:
+// resnet.py:30-50,105-110; sparse_building_blocks.py:29-34,110-117).
+//
+// Output-stationary  gather -> MFMA -> LDS-accumulate.
+//   One 256-thread workgroup owns a tile of TR (64/128/256) dst rows whose fp32 accumulators live
+//   in LDS.  It walks the filter offsets k; for each k the tile's rules are compacted into
+//   sub-chunks of 16 rules that are dealt round-robin to the wavefronts.  W[k] is streamed through
+//   LDS by LDS-DMA in slices of 16/32 input planes (double buffered, ONE barrier per slice) and is
+//   shared by all waves; src feature rows are gathered straight into MFMA A-operand registers one
+//   phase ahead (float4 per lane, 64 B per rule row and step; rule indices two offsets ahead),
+//   multiplied with v_mfma_f32_16x16x4_f32 (exact fp32), and the 16xN results are added into the LDS
+//   tile (ds_add_f32).  Rows of one k are distinct and the k-phases are barrier-separated, so the
+//   summation order is fixed: run-to-run deterministic, no global atomics; every dst row is written
+//   to HBM exactly once.  Tiles are sized so that 2-6 workgroups share a CU: the barrier / gather
+//   latency of one workgroup is covered by its neighbours' MFMAs.
+#include "common.h"
+
+#include <stdlib.h>
+
+namespace sei {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ inline f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+__device__ inline void lds_add(float *p, float v) {
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// unconditional load (clamped row) + select: conditional loads make hipcc serialise them with vmcnt(0)
+__device__ inline float4 load_a(const float *__restrict__ X, int src, int CIN, int off) {
+    const int row = src >= 0 ? src : 0;
+    float4 v = *reinterpret_cast<const float4 *>(X + (size_t)row * CIN + off);
+    if (src < 0) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    return v;
+}
+
+// one (k, slice) phase for a wave owning MS sub-chunks: straight-line, so the LDS reads of step
+// e+1 are scheduled under the MFMAs of step e.
+template <int NT, int SLJ, int MS, int MAXS, int COUT>
+__device__ __forceinline__ void compute_phase(const float *__restrict__ wb, const float4 (&a)[MAXS][SLJ],
+                                              f32x4 (&acc)[MAXS][NT], int g) {
+#pragma unroll
+    for (int jj = 0; jj < SLJ; jj++) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            float b[NT];
+#pragma unroll
+            for (int n = 0; n < NT; n++) b[n] = wb[(16 * jj + 4 * g + e) * COUT + 16 * n];
+#pragma unroll
+            for (int m = 0; m < MS; m++) {
+                const float av = e == 0 ? a[m][jj].x : e == 1 ? a[m][jj].y : e == 2 ? a[m][jj].z : a[m][jj].w;
+#pragma unroll
+                for (int n = 0; n < NT; n++) acc[m][n] = mfma16(av, b[n], acc[m][n]);
+            }
+        }
+    }
+}
+
+// Weight slice global -> LDS by LDS-DMA (global_load_lds_dwordx4): no staging registers, asynchronous.
+// The slice is contiguous in W; every wave-instruction moves 1 KiB (64 lanes x 16 B) to a
+// wave-uniform LDS base + lane*16.  PIECES = 1-KiB pieces per slice, dealt round-robin to the 4 waves.
+template <int PIECES>
+__device__ __forceinline__ void stage_slice(const float *__restrict__ wslice, float *wdst, int wave, int lane) {
+#pragma unroll
+    for (int q = 0; q < (PIECES + 3) / 4; q++) {
+        const int piece = q * 4 + wave;
+        if (piece < PIECES) {  // wave-uniform
+            const float *gp = wslice + (size_t)piece * 256 + lane * 4;
+            float *lp = wdst + (size_t)piece * 256;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gp,
+                                             (__attribute__((address_space(3))) void *)lp, 16, 0, 0);
+        }
+    }
+}
+
+template <int MAXS>
+struct RuleIdx {
+    int src[MAXS];        // lane r16: src row of rule slot r16 (A operand row)
+    uint32_t d4[MAXS];    // lane group g: packed dst rows (tile-local) of result rows 4g..4g+3
+    int ms;
+};
+
+constexpr int occ_for(int maxs, int nt, int slj) {
+    // waves per SIMD the register allocator should aim for (LDS decides the rest):
+    // accumulators + two A fragment sets + B values + ~80 registers of addressing / indices
+    const int est = maxs * nt * 4 + 2 * maxs * slj * 4 + nt + 80;
+    return est <= 132 ? 4 : (est <= 165 ? 3 : (est <= 250 ? 2 : 1));
+}
+
+// NT = 16-column tiles per wave, CS = waves sharing one sub-chunk (column split), SLJ = slice / 16,
+// MAXS = sub-chunks of one offset a wave can own.  COUT = 16*NT*CS, tile rows TR = 16*MAXS*(4/CS).
+// LDS: acc[TR][COUT] | wbuf[2][SL][COUT] | seg[K+1]
+constexpr int APAD = 0;
+
+template <int NT, int CS, int SLJ, int MAXS>
+__global__ __launch_bounds__(256, occ_for(MAXS, NT, SLJ)) void conv_tile_mfma_kernel(
+    const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ Y,
+    const int32_t *__restrict__ tile_sub_start, const int32_t *__restrict__ tile_seg,
+    const int32_t *__restrict__ sub_src, const uint8_t *__restrict__ sub_dst, int64_t n_dst, int K, int CIN) {
+    extern __shared__ float lds[];
+    constexpr int U = 4 / CS;  // units (groups of CS waves) dealing sub-chunks
+    constexpr int TR = 16 * MAXS * U;
+    constexpr int SL = 16 * SLJ;
+    constexpr int NC = NT * 16;
+    constexpr int COUT = NC * CS;
+    constexpr int PIECES = SL * COUT / 256;  // 1-KiB LDS-DMA pieces per weight slice (contiguous in W)
+    constexpr int ASTRIDE = COUT + APAD;     // accumulator row stride (floats)
+    const int tile = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int unit = wave / CS, cg = wave - unit * CS;
+    const int col0 = cg * NC;
+    const int r16 = lane & 15, g = lane >> 4;
+    float *acc_tile = lds;
+    float *wbuf = lds + (size_t)TR * ASTRIDE;
+    int *seg = reinterpret_cast<int *>(wbuf + 2 * SL * COUT);
+
+    for (int i = threadIdx.x; i <= K; i += 256) seg[i] = tile_seg[(size_t)tile * (K + 1) + i];
+    {
+        constexpr int V = COUT >> 2;
+        for (int idx = threadIdx.x; idx < TR * V; idx += 256) {
+            int r = idx / V, v = idx - r * V;
+            float4 b = bias ? *reinterpret_cast<const float4 *>(bias + 4 * v) : make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4 *>(acc_tile + (size_t)r * ASTRIDE + 4 * v) = b;
+        }
+    }
+    __syncthreads();
+
+    const int64_t sub0 = tile_sub_start[tile];
+    const int NS = CIN / SL;  // slices per offset
+
+    auto next_k = [&](int k) {  // next offset with rules in this tile (K if none)
+        if (k < K) k++;
+        while (k < K && seg[k + 1] == seg[k]) k++;
+        return __builtin_amdgcn_readfirstlane(k);
+    };
+    auto load_idx = [&](int k) {  // clamped: k == K re-reads the last offset's (unused) slots
+        RuleIdx<MAXS> r;
+        const int kk = k < K ? k : K - 1;
+        int s0 = __builtin_amdgcn_readfirstlane(seg[kk]), ns = __builtin_amdgcn_readfirstlane(seg[kk + 1]) - s0;
+        if (k >= K) ns = 0;
+        int ms = 0;
+#pragma unroll
+        for (int m = 0; m < MAXS; m++) {
+            const int s = unit + m * U;
+            const bool valid = s < ns;
+            const int64_t sb = (sub0 + s0 + (valid ? s : 0)) * SUB_SLOTS;
+            const int sv = sub_src[sb + r16];
+            const uint32_t dv = *reinterpret_cast<const uint32_t *>(sub_dst + sb + 4 * g);
+            r.src[m] = valid ? sv : -1;
+            r.d4[m] = dv;
+            if (valid) ms = m + 1;
+        }
+        r.ms = __builtin_amdgcn_readfirstlane(ms);
+        return r;
+    };
+
+    int k = next_k(-1);
+    if (k < K) {
+        int k1 = next_k(k), k2 = next_k(k1);
+        RuleIdx<MAXS> ic = load_idx(k), in1 = load_idx(k1), in2 = load_idx(k2);
+        stage_slice<PIECES>(W + (size_t)k * CIN * COUT, wbuf, wave, lane);
+        float4 a_c[MAXS][SLJ], a_n[MAXS][SLJ];
+#pragma unroll
+        for (int m = 0; m < MAXS; m++)
+#pragma unroll
+            for (int jj = 0; jj < SLJ; jj++) {
+                a_c[m][jj] = load_a(X, ic.src[m], CIN, 16 * jj + 4 * g);
+                a_n[m][jj] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        int phase = 0;
+        while (k < K) {
+            const int kw = k1 < K ? k1 : k;  // weights to prefetch after the last slice (unused at the very end)
+            f32x4 acc[MAXS][NT];
+#pragma unroll
+            for (int m = 0; m < MAXS; m++)
+#pragma unroll
+                for (int n = 0; n < NT; n++) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int s = 0; s < NS; s++) {
+                __syncthreads();  // this phase's slice has landed (vmcnt(0) + barrier); previous phase fully consumed
+                // prefetch the next phase's weight slice and A fragments while this one computes
+                const bool same_k = s + 1 < NS;
+                stage_slice<PIECES>(W + ((size_t)(same_k ? k : kw) * CIN + (size_t)(same_k ? s + 1 : 0) * SL) * COUT,
+                                    wbuf + (size_t)((phase + 1) & 1) * SL * COUT, wave, lane);
+                const int aoff = (same_k ? (s + 1) * SL : 0) + 4 * g;
+#pragma unroll
+                for (int m = 0; m < MAXS; m++)
+#pragma unroll
+                    for (int jj = 0; jj < SLJ; jj++)
+                        a_n[m][jj] = load_a(X, same_k ? ic.src[m] : in1.src[m], CIN, aoff + 16 * jj);
+                const float *wb = wbuf + (size_t)(phase & 1) * SL * COUT + col0 + r16;
+                if (MAXS == 1) {
+                    if (ic.ms == 1) compute_phase<NT, SLJ, 1, MAXS, COUT>(wb, a_c, acc, g);
+                } else if (MAXS == 2) {
+                    if (ic.ms == 1) compute_phase<NT, SLJ, 1, MAXS, COUT>(wb, a_c, acc, g);
+                    else if (ic.ms == 2) compute_phase<NT, SLJ, (MAXS >= 2 ? 2 : 1), MAXS, COUT>(wb, a_c, acc, g);
+                } else {
+                    switch (ic.ms) {
+                        case 1: compute_phase<NT, SLJ, 1, MAXS, COUT>(wb, a_c, acc, g); break;
+                        case 2: compute_phase<NT, SLJ, (MAXS >= 2 ? 2 : 1), MAXS, COUT>(wb, a_c, acc, g); break;
+                        case 3: compute_phase<NT, SLJ, (MAXS >= 3 ? 3 : 1), MAXS, COUT>(wb, a_c, acc, g); break;
+                        case 4: compute_phase<NT, SLJ, (MAXS >= 4 ? 4 : 1), MAXS, COUT>(wb, a_c, acc, g); break;
+                        default: break;
+                    }
+                }
+#pragma unroll
+                for (int m = 0; m < MAXS; m++)
+#pragma unroll
+                    for (int jj = 0; jj < SLJ; jj++) a_c[m][jj] = a_n[m][jj];
+                phase++;
+            }
+            // D[row = 4g+i][col = r16] belongs to rule slot 4g+i of the sub-chunk.  Rows of one offset are
+            // distinct and the previous offset's updates are barrier-separated: plain read-modify-write
+            // (LDS float atomics cost ~150 cycles per wave-instruction on gfx950).
+#pragma unroll
+            for (int m = 0; m < MAXS; m++) {
+                if (m < ic.ms) {
+                    // padding sits at the end of the sub-chunk: slots [0, nv) are rules
+                    const int nv = __popcll(__ballot(ic.src[m] >= 0) & 0xFFFFull);
+                    float old[4][NT];
+                    float *p[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int dd = (ic.d4[m] >> (8 * i)) & 0xFF;
+                        p[i] = acc_tile + dd * ASTRIDE + col0 + r16;
+#pragma unroll
+                        for (int n = 0; n < NT; n++) old[i][n] = p[i][16 * n];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        if (4 * g + i < nv) {
+#pragma unroll
+                            for (int n = 0; n < NT; n++) p[i][16 * n] = old[i][n] + acc[m][n][i];
+                        }
+                    }
+                }
+            }
+            ic = in1;
+            in1 = in2;
+            k = k1;
+            k1 = k2;
+            k2 = next_k(k2);
+            in2 = load_idx(k2);  // two offsets ahead: its latency never meets a barrier
+        }
+    }
+    __syncthreads();
+    // epilogue: every dst row is written once, as whole float4 row segments
+    constexpr int V = COUT >> 2;
+    const int64_t row0 = (int64_t)tile * TR;
+    for (int idx = threadIdx.x; idx < TR * V; idx += 256) {
+        int r = idx / V, v = idx - r * V;
+        if (row0 + r < n_dst)
+            *reinterpret_cast<float4 *>(Y + (size_t)(row0 + r) * COUT + 4 * v) =
+                *reinterpret_cast<const float4 *>(acc_tile + (size_t)r * ASTRIDE + 4 * v);
+    }
+}
+
+// Any channel counts (stem Cin=1, odd test sizes): same tile / sub-chunk walk, scalar FMA.
+__global__ __launch_bounds__(256) void conv_tile_generic_kernel(
+    const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ Y,
+    const int32_t *__restrict__ tile_sub_start, const int32_t *__restrict__ tile_seg,
+    const int32_t *__restrict__ sub_src, const uint8_t *__restrict__ sub_dst, int64_t n_dst, int K, int CIN, int COUT,
+    int TR) {
+    extern __shared__ float lds[];
+    const int tile = blockIdx.x;
+    float *acc = lds;
+    for (int idx = threadIdx.x; idx < TR * COUT; idx += 256) acc[idx] = bias ? bias[idx % COUT] : 0.f;
+    __syncthreads();
+    const int64_t sub0 = tile_sub_start[tile];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r16 = lane & 15, g = lane >> 4;
+    for (int k = 0; k < K; k++) {
+        const int s0 = tile_seg[(size_t)tile * (K + 1) + k], s1 = tile_seg[(size_t)tile * (K + 1) + k + 1];
+        const float *Wk = W + (size_t)k * CIN * COUT;
+        for (int s = s0 + wave; s < s1; s += 4) {
+            int64_t slot = (sub0 + s) * SUB_SLOTS + r16;
+            int src = sub_src[slot], d = sub_dst[slot];
+            if (src < 0) continue;
+            const float *xr = X + (size_t)src * CIN;
+            for (int co = g; co < COUT; co += 4) {
+                float sum = 0.f;
+                for (int ci = 0; ci < CIN; ci++) sum = fmaf(xr[ci], Wk[(size_t)ci * COUT + co], sum);
+                acc[d * COUT + co] += sum;  // rows of one offset are distinct: no atomics needed
+            }
+        }
+        __syncthreads();  // keeps the per-row sum order fixed (k-phases), as in the MFMA kernel
+    }
+    const int64_t row0 = (int64_t)tile * TR;
+    for (int idx = threadIdx.x; idx < TR * COUT; idx += 256) {
+        int r = idx / COUT;
+        if (row0 + r < n_dst) Y[(size_t)row0 * COUT + idx] = acc[idx];
+    }
+}
+
+__global__ void fill_bias_kernel(float *Y, int64_t n, int C, const float *bias) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n * C) Y[t] = bias ? bias[t % C] : 0.f;
+}
+
+struct FwdPlan {
+    bool mfma;
+    int nt, cs, slj, maxs, tile_rows;
+    size_t lds_bytes;
+};
+
+static size_t fwd_lds(int tile_rows, int nOut, int slj, int K) {
+    return ((size_t)tile_rows * (nOut + APAD) + 2 * 16 * slj * nOut) * sizeof(float) + (K + 1) * sizeof(int);
+}
+
+// SEI_FWD_PLAN="maxs,cs,slj" overrides the default tiling (kernel experiments only)
+static bool env_plan(int *maxs, int *cs, int *slj) {
+    const char *e = getenv("SEI_FWD_PLAN");
+    if (!e) return false;
+    return sscanf(e, "%d,%d,%d", maxs, cs, slj) == 3;
+}
+
+static FwdPlan plan_forward(int nIn, int nOut, int K) {
+    FwdPlan p{};
+    p.mfma = (nIn % 16 == 0) && (nOut % 16 == 0) && nIn >= 16 && nOut <= 192;
+    if (p.mfma) {
+        // the tile size depends on nOut only (the rulebook variant is chosen from it)
+        if (nOut <= 96) {
+            p.maxs = 2; p.cs = 1;   // 128-row tiles
+        } else {
+            p.maxs = 1; p.cs = 1;   // 64-row tiles, wide accumulators
+        }
+        p.slj = (nIn % 32 == 0) ? 2 : 1;
+        int em, ec, es;
+        if (env_plan(&em, &ec, &es)) {
+            if ((nOut / 16) % ec == 0 && (em == 1 || em == 2 || em == 4) && (ec == 1 || ec == 2)) {
+                p.maxs = em; p.cs = ec;
+                if (es == 1 || (es == 2 && nIn % 32 == 0)) p.slj = es;
+            }
+        }
+        p.nt = nOut / 16 / p.cs;
+        p.tile_rows = 16 * p.maxs * (4 / p.cs);
+        // keep two workgroups per CU when halving the slice allows it
+        if (p.slj == 2 && fwd_lds(p.tile_rows, nOut, 2, K) > 80 * 1024 && fwd_lds(p.tile_rows, nOut, 1, K) <= 80 * 1024 &&
+            !getenv("SEI_FWD_PLAN"))
+            p.slj = 1;
+        p.lds_bytes = fwd_lds(p.tile_rows, nOut, p.slj, K);
+        if (p.lds_bytes > 160 * 1024) p.mfma = false;
+    }
+    if (!p.mfma) {
+        p.tile_rows = (size_t)256 * nOut * sizeof(float) <= 96 * 1024 ? 256 : 128;
+        p.lds_bytes = (size_t)p.tile_rows * nOut * sizeof(float);
+    }
+    return p;
+}
+
+int conv_tile_rows(int nIn, int nOut) { return plan_forward(nIn, nOut, 27).tile_rows; }
+
+template <int NT, int CS, int SLJ, int MAXS>
+static int launch_mfma(const TiledRules &t, const FwdPlan &p, const float *X, const float *W, const float *bias,
+                       float *Y, int nIn, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        SEI_HIP(hipFuncSetAttribute((const void *)conv_tile_mfma_kernel<NT, CS, SLJ, MAXS>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    conv_tile_mfma_kernel<NT, CS, SLJ, MAXS><<<t.n_tiles, 256, p.lds_bytes, st>>>(
+        X, W, bias, Y, t.tile_sub_start, t.tile_seg, t.sub_src, t.sub_dst, t.n_dst, t.K, nIn);
+    SEI_LAUNCH_CHECK();
+    return 0;
+}
+
+#define FWD_CASE(NT_, CS_, SLJ_, MAXS_)                                            \
+    if (p.nt == NT_ && p.cs == CS_ && p.slj == SLJ_ && p.maxs == MAXS_)            \
+        return launch_mfma<NT_, CS_, SLJ_, MAXS_>(t, p, X, W, bias, Y, nIn, st);
+#define FWD_BOTH_SLJ(NT_, CS_, MAXS_) FWD_CASE(NT_, CS_, 1, MAXS_) FWD_CASE(NT_, CS_, 2, MAXS_)
+
+int conv_forward(const TiledRules &t, const float *X, const float *W, const float *bias, float *Y, int nIn, int nOut,
+                 hipStream_t st) {
+    if (t.n_dst == 0) return 0;
+    if (t.n_sub == 0) {
+        int64_t tot = t.n_dst * nOut;
+        fill_bias_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, st>>>(Y, t.n_dst, nOut, bias);
+        SEI_LAUNCH_CHECK();
+        return 0;
+    }
+    FwdPlan p = plan_forward(nIn, nOut, t.K);
+    if (p.tile_rows != t.tile_rows) SEI_FAIL("conv_forward: rulebook tile size does not match the kernel plan");
+    if (p.mfma) {
+        // default plans
+        FWD_BOTH_SLJ(1, 1, 2) FWD_BOTH_SLJ(2, 1, 2) FWD_BOTH_SLJ(3, 1, 2) FWD_BOTH_SLJ(4, 1, 2) FWD_BOTH_SLJ(5, 1, 2)
+        FWD_BOTH_SLJ(6, 1, 2)
+        FWD_BOTH_SLJ(7, 1, 1) FWD_BOTH_SLJ(8, 1, 1) FWD_BOTH_SLJ(9, 1, 1) FWD_BOTH_SLJ(10, 1, 1) FWD_BOTH_SLJ(11, 1, 1)
+        FWD_BOTH_SLJ(12, 1, 1)
+        // alternates reachable through SEI_FWD_PLAN (kernel experiments)
+        FWD_CASE(2, 1, 2, 4) FWD_CASE(4, 1, 2, 4) FWD_CASE(6, 1, 2, 4)
+        FWD_CASE(2, 1, 2, 1) FWD_CASE(4, 1, 2, 1) FWD_CASE(6, 1, 2, 1)
+        FWD_CASE(4, 2, 2, 2) FWD_CASE(5, 2, 2, 2) FWD_CASE(6, 2, 2, 2) FWD_CASE(3, 2, 2, 2)
+        FWD_CASE(4, 2, 2, 4) FWD_CASE(5, 2, 2, 4) FWD_CASE(6, 2, 2, 4)
+        FWD_CASE(8, 1, 2, 2) FWD_CASE(4, 2, 1, 2) FWD_CASE(5, 2, 1, 2) FWD_CASE(6, 2, 1, 2)
+        SEI_FAIL("conv_forward: no MFMA instantiation for this plan");
+    }
+    if (p.lds_bytes > 160 * 1024) SEI_FAIL("conv: nOut too large for the generic kernel");
+    static bool attr_set = false;
+    if (!attr_set) {
+        SEI_HIP(hipFuncSetAttribute((const void *)conv_tile_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    160 * 1024));
+        attr_set = true;
+    }
+    conv_tile_generic_kernel<<<t.n_tiles, 256, p.lds_bytes, st>>>(X, W, bias, Y, t.tile_sub_start, t.tile_seg, t.sub_src,
+                                                                 t.sub_dst, t.n_dst, t.K, nIn, nOut, t.tile_rows);
+    SEI_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace sei
