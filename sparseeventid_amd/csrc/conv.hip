@@ -83,6 +83,59 @@ __device__ inline int dw_build_list(const int32_t *__restrict__ tile_sub_start, 
     return total;
 }
 
+// rule indices of one sub-chunk, one slot per lane r16 (replicated over the 4 lane groups)
+struct DwItem {
+    int src;       // src row of slot r16, -1 = padding / no item
+    int64_t drow;  // global dst row of slot r16
+};
+
+__device__ __forceinline__ DwItem dw_load_item(const int *list_sub, const int *list_tile, int li, int total, int TR,
+                                               const int32_t *__restrict__ sub_src,
+                                               const uint8_t *__restrict__ sub_dst, int r16) {
+    // clamped + select: never branch around a load (hipcc would serialise it with vmcnt(0))
+    const bool valid = li < total;
+    const int lc = valid ? li : 0;
+    const int64_t c = valid ? list_sub[lc] : 0;
+    const int64_t rowbase = valid ? (int64_t)list_tile[lc] * TR : 0;
+    const int sv = sub_src[c * SUB_SLOTS + r16];
+    const int dv = sub_dst[c * SUB_SLOTS + r16];
+    DwItem it;
+    it.src = valid ? sv : -1;
+    it.drow = rowbase + dv;
+    return it;
+}
+
+template <int MT, int NT>
+struct DwOps {
+    float a[MT], b[NT];
+    int any;  // wave-uniform: some slot of this step holds a rule
+};
+
+// operands of MFMA step q (rules 4q..4q+3 of the sub-chunk): lane (g, r16) holds X[src_g][ci0+16m+r16], dY[dst_g][16n+r16]
+template <int MT, int NT>
+__device__ __forceinline__ DwOps<MT, NT> dw_load_ops(const DwItem &it, int q, int g, int r16,
+                                                     const float *__restrict__ X, const float *__restrict__ dY, int CIN,
+                                                     int COUT, int ci0) {
+    DwOps<MT, NT> o;
+    const int src = __shfl(it.src, 4 * q + g);
+    const int64_t drow = __shfl(it.drow, 4 * q + g);
+    const bool ok = src >= 0;
+    const float *xr = X + (size_t)(ok ? src : 0) * CIN + ci0 + r16;
+    const float *yr = dY + (size_t)(ok ? drow : 0) * COUT + r16;
+#pragma unroll
+    for (int m = 0; m < MT; m++) {
+        float v = xr[16 * m];
+        o.a[m] = ok ? v : 0.f;
+    }
+#pragma unroll
+    for (int n = 0; n < NT; n++) {
+        float v = yr[16 * n];
+        o.b[n] = ok ? v : 0.f;
+    }
+    o.any = __any(ok);
+    return o;
+}
+
 template <int MT, int NT>
 __global__ __launch_bounds__(256) void conv_dw_mfma_kernel(
     const float *__restrict__ X, const float *__restrict__ dY, const int32_t *__restrict__ tile_sub_start,
@@ -106,25 +159,28 @@ __global__ __launch_bounds__(256) void conv_dw_mfma_kernel(
     const int t_end = min(n_tiles, t_begin + tiles_per_split);
     for (int tb = t_begin; tb < t_end; tb += DW_TILES_PER_ITER) {
         const int total = dw_build_list(tile_sub_start, seg_start, n_tiles, k, tb, t_end, list_sub, list_tile, scan_tmp);
-        for (int li = wave; li < total; li += 4) {
-            const int64_t c = list_sub[li];
-            const int64_t rowbase = (int64_t)list_tile[li] * TR;
-#pragma unroll 2
-            for (int q = 0; q < SUB_SLOTS / 4; q++) {
-                int src = sub_src[c * SUB_SLOTS + 4 * q + g];
-                if (!__any(src >= 0)) continue;
-                int dl = sub_dst[c * SUB_SLOTS + 4 * q + g];
-                float a[MT], b[NT];
-                const float *xr = X + (size_t)(src >= 0 ? src : 0) * CIN + ci0 + r16;
-                const float *yr = dY + (size_t)(rowbase + dl) * COUT + r16;
+        if (total > 0) {
+            // software pipeline: item indices one item ahead, MFMA operands one step ahead
+            int li = wave;
+            DwItem cur = dw_load_item(list_sub, list_tile, li, total, TR, sub_src, sub_dst, r16);
+            DwItem nxt = dw_load_item(list_sub, list_tile, li + 4, total, TR, sub_src, sub_dst, r16);
+            DwOps<MT, NT> oc = dw_load_ops<MT, NT>(cur, 0, g, r16, X, dY, CIN, COUT, ci0);
+            while (li < total) {
 #pragma unroll
-                for (int m = 0; m < MT; m++) a[m] = src >= 0 ? xr[16 * m] : 0.f;
+                for (int q = 0; q < SUB_SLOTS / 4; q++) {
+                    DwOps<MT, NT> on = q + 1 < SUB_SLOTS / 4 ? dw_load_ops<MT, NT>(cur, q + 1, g, r16, X, dY, CIN, COUT, ci0)
+                                                             : dw_load_ops<MT, NT>(nxt, 0, g, r16, X, dY, CIN, COUT, ci0);
+                    if (oc.any) {
 #pragma unroll
-                for (int n = 0; n < NT; n++) b[n] = src >= 0 ? yr[16 * n] : 0.f;
+                        for (int m = 0; m < MT; m++)
 #pragma unroll
-                for (int m = 0; m < MT; m++)
-#pragma unroll
-                    for (int n = 0; n < NT; n++) acc[m][n] = mfma16(a[m], b[n], acc[m][n]);
+                            for (int n = 0; n < NT; n++) acc[m][n] = mfma16(oc.a[m], oc.b[n], acc[m][n]);
+                    }
+                    oc = on;
+                }
+                li += 4;
+                cur = nxt;
+                nxt = dw_load_item(list_sub, list_tile, li + 4, total, TR, sub_src, sub_dst, r16);
             }
         }
         __syncthreads();
@@ -153,19 +209,21 @@ __global__ __launch_bounds__(256) void conv_dw_mfma_kernel(
 }
 
 // dW for tiny nIn (stem: nIn = 1): HBM-bound gather of dY rows; lane = output plane, the 64/COUT lane groups
-// take different rule slots; fixed-order reductions.
-template <int CIN>
+// take different rule slots; all loads of a sub-chunk are issued together; fixed-order reductions.
+template <int CIN, int COUT>
 __global__ __launch_bounds__(256) void conv_dw_smallcin_kernel(
     const float *__restrict__ X, const float *__restrict__ dY, const int32_t *__restrict__ tile_sub_start,
     const int32_t *__restrict__ seg_start, const int32_t *__restrict__ sub_src, const uint8_t *__restrict__ sub_dst,
-    int n_tiles, int TR, int COUT, int tiles_per_split, int S, float *__restrict__ slab) {
+    int n_tiles, int TR, int tiles_per_split, int S, float *__restrict__ slab) {
     __shared__ int list_sub[DW_LIST_CAP];
     __shared__ int list_tile[DW_LIST_CAP];
     __shared__ int scan_tmp[8];
     __shared__ float red[4][CIN][64];
     const int k = blockIdx.x, s = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int groups = 64 / COUT;          // rule slots handled per step by one wave
+    const int r16 = lane & 15;
+    constexpr int groups = 64 / COUT;  // rule slots handled per step by one wave (COUT in {16, 32, 64})
+    constexpr int STEPS = SUB_SLOTS / groups;
     const int co = lane % COUT, grp = lane / COUT;
     float acc[CIN];
 #pragma unroll
@@ -174,15 +232,29 @@ __global__ __launch_bounds__(256) void conv_dw_smallcin_kernel(
     const int t_end = min(n_tiles, t_begin + tiles_per_split);
     for (int tb = t_begin; tb < t_end; tb += DW_TILES_PER_ITER) {
         const int total = dw_build_list(tile_sub_start, seg_start, n_tiles, k, tb, t_end, list_sub, list_tile, scan_tmp);
-        for (int li = wave; li < total; li += 4) {
-            const int64_t c = list_sub[li];
-            const int64_t rowbase = (int64_t)list_tile[li] * TR;
-            for (int q = grp; q < SUB_SLOTS; q += groups) {
-                int src = sub_src[c * SUB_SLOTS + q];
-                if (src < 0) continue;
-                float dy = dY[(size_t)(rowbase + sub_dst[c * SUB_SLOTS + q]) * COUT + co];
+        if (total > 0) {
+            int li = wave;
+            DwItem cur = dw_load_item(list_sub, list_tile, li, total, TR, sub_src, sub_dst, r16);
+            while (li < total) {
+                DwItem nxt = dw_load_item(list_sub, list_tile, li + 4, total, TR, sub_src, sub_dst, r16);
+                float dyv[STEPS], xv[STEPS][CIN];
 #pragma unroll
-                for (int ci = 0; ci < CIN; ci++) acc[ci] = fmaf(X[(size_t)src * CIN + ci], dy, acc[ci]);
+                for (int q = 0; q < STEPS; q++) {
+                    const int slot = q * groups + grp;
+                    const int src = __shfl(cur.src, slot);
+                    const int64_t drow = __shfl(cur.drow, slot);
+                    const bool ok = src >= 0;
+                    float dv = dY[(size_t)(ok ? drow : 0) * COUT + co];
+                    dyv[q] = ok ? dv : 0.f;
+#pragma unroll
+                    for (int ci = 0; ci < CIN; ci++) xv[q][ci] = X[(size_t)(ok ? src : 0) * CIN + ci];
+                }
+#pragma unroll
+                for (int q = 0; q < STEPS; q++)
+#pragma unroll
+                    for (int ci = 0; ci < CIN; ci++) acc[ci] = fmaf(xv[q][ci], dyv[q], acc[ci]);
+                li += 4;
+                cur = nxt;
             }
         }
         __syncthreads();
@@ -307,9 +379,11 @@ int conv_backward_weight(const TiledRules &t, const float *X, const float *dY, f
     if (mfma_ok)
         rc = dispatch_dw(mt, nt, t, X, dY, nIn, nOut, tps, S, slab, st);
     else if (small) {
-#define SM(CIN_) conv_dw_smallcin_kernel<CIN_><<<grid, 256, 0, st>>>(X, dY, t.tile_sub_start, t.seg_start, t.sub_src, \
-                                                                      t.sub_dst, t.n_tiles, t.tile_rows, nOut, tps, S, slab)
-        if (nIn == 1) SM(1); else if (nIn == 2) SM(2); else if (nIn == 3) SM(3); else SM(4);
+#define SM(CIN_, COUT_) conv_dw_smallcin_kernel<CIN_, COUT_><<<grid, 256, 0, st>>>(                              \
+    X, dY, t.tile_sub_start, t.seg_start, t.sub_src, t.sub_dst, t.n_tiles, t.tile_rows, tps, S, slab)
+#define SMC(CIN_) if (nOut == 16) SM(CIN_, 16); else if (nOut == 32) SM(CIN_, 32); else SM(CIN_, 64)
+        if (nIn == 1) { SMC(1); } else if (nIn == 2) { SMC(2); } else if (nIn == 3) { SMC(3); } else { SMC(4); }
+#undef SMC
 #undef SM
         if (hipGetLastError() != hipSuccess) rc = 1;
     } else {
