@@ -70,9 +70,13 @@ int sei_subm_rulebook(sei_metadata_t *m, const int32_t spatial[3], const int32_t
 int sei_conv_rulebook(sei_metadata_t *m, const int32_t spatial_in[3], const int32_t size[3],
                       const int32_t stride[3], sei_stream_t stream, sei_rulebook_t **rb,
                       int32_t spatial_out[3]);
-/* info[0]=n_dst rows, [1]=n_src rows, [2]=K, [3]=rules, [4]=sub-chunks (16 rule slots each = MFMA row
- * blocks executed), [5]=tiles, [6]=sub-chunks, [7]=tile rows (256 or 128) */
+/* The tiled rule lists are built lazily, per tile size (256/128/64 dst rows) the conv kernels ask for.
+ * info[0]=n_dst rows, [1]=n_src rows, [2]=K; for the first built tile size (zeros if none yet):
+ * [3]=rules, [4]=sub-chunks (16 rule slots each = MFMA row blocks executed), [5]=tiles, [6]=sub-chunks,
+ * [7]=tile rows. */
 int sei_rulebook_info(const sei_rulebook_t *rb, int64_t info[8]);
+/* force the build of one tile size (tests / inspection).  Synchronises `stream`. */
+int sei_rulebook_build(sei_rulebook_t *rb, int32_t tile_rows, sei_stream_t stream);
 /* copy the rules out as k-major (in,out) lists for inspection/tests: start[K+1] (host),
  * rules_in/out device int32 [rules].  Synchronises. */
 int sei_rulebook_export(sei_rulebook_t *rb, int64_t *start_host, int32_t *rules_in_dev,

@@ -241,13 +241,7 @@ int sei_subm_rulebook(sei_metadata_t *m, const int32_t spatial[3], const int32_t
         rb->size[d] = filter[d];
         rb->stride[d] = 1;
     }
-    rb->lin = rb->lout = l;
-    const TiledRules *t;
-    int rc = get_tiled(rb, false, 128, &t, (hipStream_t)stream);
-    if (rc) {
-        delete rb;
-        return rc;
-    }
+    rb->lin = rb->lout = l;  // tiled rule lists are built lazily, per tile size the kernels ask for
     m->rulebooks.push_back(rb);
     *rb_out = rb;
     return 0;
@@ -272,8 +266,6 @@ int sei_conv_rulebook(sei_metadata_t *m, const int32_t spatial_in[3], const int3
         rb->stride[d] = stride[d];
     }
     int rc = build_strided_level(m, l, size, stride, rb, (hipStream_t)stream);
-    const TiledRules *t;
-    if (!rc) rc = get_tiled(rb, false, 128, &t, (hipStream_t)stream);
     if (rc) {
         delete rb;
         return rc;
@@ -286,11 +278,21 @@ int sei_conv_rulebook(sei_metadata_t *m, const int32_t spatial_in[3], const int3
 
 int sei_rulebook_info(const sei_rulebook_t *rb_c, int64_t info[8]) {
     sei_rulebook_t *rb = const_cast<sei_rulebook_t *>(rb_c);
-    const TiledRules *t;
-    SEI_TRY(get_any_tiled(rb, false, &t, nullptr));
-    info[0] = t->n_dst; info[1] = t->n_src; info[2] = t->K; info[3] = t->n_rules;
-    info[4] = t->n_sub; info[5] = t->n_tiles; info[6] = t->n_sub; info[7] = t->tile_rows;
+    std::lock_guard<std::mutex> lk(rb->mu);
+    info[0] = rb->lout->n; info[1] = rb->lin->n; info[2] = rb->size[0] * rb->size[1] * rb->size[2];
+    info[3] = info[4] = info[5] = info[6] = info[7] = 0;
+    for (int v = 0; v < SEI_NVARIANT; v++)
+        if (rb->fwd[v].built) {
+            const TiledRules &t = rb->fwd[v];
+            info[3] = t.n_rules; info[4] = t.n_sub; info[5] = t.n_tiles; info[6] = t.n_sub; info[7] = t.tile_rows;
+            break;
+        }
     return 0;
+}
+
+int sei_rulebook_build(sei_rulebook_t *rb, int32_t tile_rows, sei_stream_t stream) {
+    const TiledRules *t;
+    return get_tiled(rb, false, tile_rows, &t, (hipStream_t)stream);
 }
 
 int sei_rulebook_export(sei_rulebook_t *rb, int64_t *start_host, int32_t *rules_in_dev, int32_t *rules_out_dev,
@@ -310,8 +312,21 @@ int sei_conv_forward(sei_rulebook_t *rb, const float *X, const float *W, const f
     hipStream_t st = (hipStream_t)stream;
     const TiledRules *t;
     SEI_TRY(get_tiled(rb, false, conv_tile_rows(nIn, nOut), &t, st));
-    ProfScope ps(PROF_CONV_FWD, st, 2.0 * t->n_rules * nIn * nOut, conv_bytes(*t, nIn, nOut));
-    return conv_forward(*t, X, W, bias, Y, nIn, nOut, st);
+    const int cgp = conv_col_group(nIn, nOut);
+    if (cgp == 0) {
+        ProfScope ps(PROF_CONV_FWD, st, 2.0 * t->n_rules * nIn * nOut, conv_bytes(*t, nIn, nOut));
+        return conv_forward(*t, X, W, bias, Y, nIn, nOut, st);
+    }
+    // the MFMA kernel reads B operands with wide LDS loads from column-permuted weights (tiny copy, <= 4 MB)
+    float *Wp;
+    SEI_TRY(pool_alloc_t(&Wp, (size_t)t->K * nIn * nOut));
+    int rc = conv_transform_weights(W, Wp, t->K, nIn, nOut, false, false, cgp, st);
+    if (!rc) {
+        ProfScope ps(PROF_CONV_FWD, st, 2.0 * t->n_rules * nIn * nOut, conv_bytes(*t, nIn, nOut));
+        rc = conv_forward(*t, X, Wp, bias, Y, nIn, nOut, st);
+    }
+    pool_free(Wp);
+    return rc;
 }
 
 int sei_conv_backward_input(sei_rulebook_t *rb, const float *dY, const float *W, float *dX, int32_t nIn, int32_t nOut,
@@ -323,7 +338,8 @@ int sei_conv_backward_input(sei_rulebook_t *rb, const float *dY, const float *W,
     SEI_TRY(get_tiled(rb, true, conv_tile_rows(nOut, nIn), &t, st));
     float *Wt;
     SEI_TRY(pool_alloc_t(&Wt, (size_t)t->K * nIn * nOut));
-    int rc = conv_transform_weights(W, Wt, t->K, nIn, nOut, rb->submanifold, st);
+    // Wt[k'][co][ci] = W[K-1-k' (submanifold mirror) or k'][ci][co], columns (ci) permuted for the kernel
+    int rc = conv_transform_weights(W, Wt, t->K, nIn, nOut, true, rb->submanifold, conv_col_group(nOut, nIn), st);
     if (!rc) {
         ProfScope ps(PROF_CONV_BWD_IN, st, 2.0 * t->n_rules * nIn * nOut, conv_bytes(*t, nOut, nIn));
         rc = conv_forward(*t, dY, Wt, nullptr, dX, nOut, nIn, st);

@@ -25,22 +25,46 @@ __device__ inline void lds_add(float *p, float v) {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// Wt[k][co][ci] = W[flip ? K-1-k : k][ci][co]
-__global__ void transform_weights_kernel(const float *__restrict__ W, float *__restrict__ Wt, int K, int nIn, int nOut,
-                                         int flip) {
+// position of column c inside a column group of NT = width/16 tiles (see load_b in conv_fwd.hip)
+__device__ inline int permute_col(int c, int width) {
+    if (width == 0) return c;
+    const int grp = c / width, cl = c - grp * width;
+    const int nt = width / 16, b4 = nt / 4, rem = nt % 4;
+    int pos;
+    if (cl < 64 * b4) {
+        const int b = cl / 64, w = cl % 64;
+        pos = 64 * b + 4 * (w % 16) + w / 16;
+    } else {
+        const int c2 = cl - 64 * b4, j = c2 / 16, r = c2 % 16;
+        if (rem == 1 || (rem == 3 && j == 2))
+            pos = 64 * b4 + (rem == 3 ? 32 : 0) + r;
+        else
+            pos = 64 * b4 + 2 * r + j;
+    }
+    return grp * width + pos;
+}
+
+__global__ void transform_weights_kernel(const float *__restrict__ W, float *__restrict__ Wout, int K, int nIn, int nOut,
+                                         int transpose, int flip, int col_group) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t per = (int64_t)nIn * nOut;
     if (t >= K * per) return;
     int k = (int)(t / per);
     int rem = (int)(t - k * per);
-    int co = rem / nIn, ci = rem - co * nIn;
-    int ks = flip ? K - 1 - k : k;
-    Wt[t] = W[(size_t)ks * per + (size_t)ci * nOut + co];
+    int ci = rem / nOut, co = rem - ci * nOut;  // coalesced read of W
+    int ks = flip ? K - 1 - k : k;              // destination offset index
+    float v = W[t];
+    if (transpose)
+        Wout[(size_t)ks * per + (size_t)co * nIn + permute_col(ci, col_group)] = v;
+    else
+        Wout[(size_t)ks * per + (size_t)ci * nOut + permute_col(co, col_group)] = v;
 }
 
-int conv_transform_weights(const float *W, float *Wt, int K, int nIn, int nOut, bool flip, hipStream_t st) {
+int conv_transform_weights(const float *W, float *Wout, int K, int nIn, int nOut, bool transpose, bool flip, int col_group,
+                           hipStream_t st) {
     int64_t tot = (int64_t)K * nIn * nOut;
-    transform_weights_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, st>>>(W, Wt, K, nIn, nOut, flip ? 1 : 0);
+    transform_weights_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, st>>>(W, Wout, K, nIn, nOut, transpose ? 1 : 0,
+                                                                           flip ? 1 : 0, col_group);
     SEI_LAUNCH_CHECK();
     return 0;
 }

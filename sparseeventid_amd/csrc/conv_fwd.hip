@@ -35,18 +35,36 @@ __device__ inline float4 load_a(const float *__restrict__ X, int src, int CIN, i
     return v;
 }
 
+// B operands of one input plane for the wave's NT column tiles.  The weight columns of every column
+// group are stored permuted (conv_permute_col) so that lane r16 finds the values of 4 (2, 1) column
+// tiles in ONE ds_read_b128 (b64, b32): position 64b + 4r + j holds column 64b + 16j + r.
+template <int NT>
+__device__ __forceinline__ void load_b(const float *__restrict__ wrow, int r16, float (&b)[NT]) {
+    constexpr int B4 = NT / 4, REM = NT % 4;
+#pragma unroll
+    for (int q = 0; q < B4; q++) {
+        const float4 v = *reinterpret_cast<const float4 *>(wrow + 64 * q + 4 * r16);
+        b[4 * q + 0] = v.x; b[4 * q + 1] = v.y; b[4 * q + 2] = v.z; b[4 * q + 3] = v.w;
+    }
+    if (REM >= 2) {
+        const float2 v = *reinterpret_cast<const float2 *>(wrow + 64 * B4 + 2 * r16);
+        b[4 * B4 + 0] = v.x; b[4 * B4 + 1] = v.y;
+    }
+    if (REM == 1) b[4 * B4] = wrow[64 * B4 + r16];
+    if (REM == 3) b[4 * B4 + 2] = wrow[64 * B4 + 32 + r16];
+}
+
 // one (k, slice) phase for a wave owning MS sub-chunks: straight-line, so the LDS reads of step
 // e+1 are scheduled under the MFMAs of step e.
 template <int NT, int SLJ, int MS, int MAXS, int COUT>
 __device__ __forceinline__ void compute_phase(const float *__restrict__ wb, const float4 (&a)[MAXS][SLJ],
-                                              f32x4 (&acc)[MAXS][NT], int g) {
+                                              f32x4 (&acc)[MAXS][NT], int g, int r16) {
 #pragma unroll
     for (int jj = 0; jj < SLJ; jj++) {
 #pragma unroll
         for (int e = 0; e < 4; e++) {
             float b[NT];
-#pragma unroll
-            for (int n = 0; n < NT; n++) b[n] = wb[(16 * jj + 4 * g + e) * COUT + 16 * n];
+            load_b<NT>(wb + (16 * jj + 4 * g + e) * COUT, r16, b);
 #pragma unroll
             for (int m = 0; m < MS; m++) {
                 const float av = e == 0 ? a[m][jj].x : e == 1 ? a[m][jj].y : e == 2 ? a[m][jj].z : a[m][jj].w;
@@ -188,18 +206,18 @@ __global__ __launch_bounds__(256, occ_for(MAXS, NT, SLJ)) void conv_tile_mfma_ke
 #pragma unroll
                     for (int jj = 0; jj < SLJ; jj++)
                         a_n[m][jj] = load_a(X, same_k ? ic.src[m] : in1.src[m], CIN, aoff + 16 * jj);
-                const float *wb = wbuf + (size_t)(phase & 1) * SL * COUT + col0 + r16;
+                const float *wb = wbuf + (size_t)(phase & 1) * SL * COUT + col0;
                 if (MAXS == 1) {
-                    if (ic.ms == 1) compute_phase<NT, SLJ, 1, MAXS, COUT>(wb, a_c, acc, g);
+                    if (ic.ms == 1) compute_phase<NT, SLJ, 1, MAXS, COUT>(wb, a_c, acc, g, r16);
                 } else if (MAXS == 2) {
-                    if (ic.ms == 1) compute_phase<NT, SLJ, 1, MAXS, COUT>(wb, a_c, acc, g);
-                    else if (ic.ms == 2) compute_phase<NT, SLJ, (MAXS >= 2 ? 2 : 1), MAXS, COUT>(wb, a_c, acc, g);
+                    if (ic.ms == 1) compute_phase<NT, SLJ, 1, MAXS, COUT>(wb, a_c, acc, g, r16);
+                    else if (ic.ms == 2) compute_phase<NT, SLJ, (MAXS >= 2 ? 2 : 1), MAXS, COUT>(wb, a_c, acc, g, r16);
                 } else {
                     switch (ic.ms) {
-                        case 1: compute_phase<NT, SLJ, 1, MAXS, COUT>(wb, a_c, acc, g); break;
-                        case 2: compute_phase<NT, SLJ, (MAXS >= 2 ? 2 : 1), MAXS, COUT>(wb, a_c, acc, g); break;
-                        case 3: compute_phase<NT, SLJ, (MAXS >= 3 ? 3 : 1), MAXS, COUT>(wb, a_c, acc, g); break;
-                        case 4: compute_phase<NT, SLJ, (MAXS >= 4 ? 4 : 1), MAXS, COUT>(wb, a_c, acc, g); break;
+                        case 1: compute_phase<NT, SLJ, 1, MAXS, COUT>(wb, a_c, acc, g, r16); break;
+                        case 2: compute_phase<NT, SLJ, (MAXS >= 2 ? 2 : 1), MAXS, COUT>(wb, a_c, acc, g, r16); break;
+                        case 3: compute_phase<NT, SLJ, (MAXS >= 3 ? 3 : 1), MAXS, COUT>(wb, a_c, acc, g, r16); break;
+                        case 4: compute_phase<NT, SLJ, (MAXS >= 4 ? 4 : 1), MAXS, COUT>(wb, a_c, acc, g, r16); break;
                         default: break;
                     }
                 }
@@ -308,10 +326,11 @@ static size_t fwd_lds(int tile_rows, int nOut, int slj, int K) {
 }
 
 // SEI_FWD_PLAN="maxs,cs,slj" overrides the default tiling (kernel experiments only)
-static bool env_plan(int *maxs, int *cs, int *slj) {
-    const char *e = getenv("SEI_FWD_PLAN");
+static bool env_plan(int nOut, int *maxs, int *cs, int *slj) {
+    const char *e = getenv("SEI_FWD_PLAN");  // "maxs,cs,slj,nOut"
     if (!e) return false;
-    return sscanf(e, "%d,%d,%d", maxs, cs, slj) == 3;
+    int no = 0;
+    return sscanf(e, "%d,%d,%d,%d", maxs, cs, slj, &no) == 4 && no == nOut;
 }
 
 static FwdPlan plan_forward(int nIn, int nOut, int K) {
@@ -326,7 +345,8 @@ static FwdPlan plan_forward(int nIn, int nOut, int K) {
         }
         p.slj = (nIn % 32 == 0) ? 2 : 1;
         int em, ec, es;
-        if (env_plan(&em, &ec, &es)) {
+        const bool forced = env_plan(nOut, &em, &ec, &es);
+        if (forced) {
             if ((nOut / 16) % ec == 0 && (em == 1 || em == 2 || em == 4) && (ec == 1 || ec == 2)) {
                 p.maxs = em; p.cs = ec;
                 if (es == 1 || (es == 2 && nIn % 32 == 0)) p.slj = es;
@@ -336,7 +356,7 @@ static FwdPlan plan_forward(int nIn, int nOut, int K) {
         p.tile_rows = 16 * p.maxs * (4 / p.cs);
         // keep two workgroups per CU when halving the slice allows it
         if (p.slj == 2 && fwd_lds(p.tile_rows, nOut, 2, K) > 80 * 1024 && fwd_lds(p.tile_rows, nOut, 1, K) <= 80 * 1024 &&
-            !getenv("SEI_FWD_PLAN"))
+            !forced)
             p.slj = 1;
         p.lds_bytes = fwd_lds(p.tile_rows, nOut, p.slj, K);
         if (p.lds_bytes > 160 * 1024) p.mfma = false;
@@ -349,6 +369,12 @@ static FwdPlan plan_forward(int nIn, int nOut, int K) {
 }
 
 int conv_tile_rows(int nIn, int nOut) { return plan_forward(nIn, nOut, 27).tile_rows; }
+
+// column-group width (floats) whose columns the forward kernel expects permuted; 0 = generic kernel, no permutation
+int conv_col_group(int nIn, int nOut) {
+    FwdPlan p = plan_forward(nIn, nOut, 27);
+    return p.mfma ? p.nt * 16 : 0;
+}
 
 template <int NT, int CS, int SLJ, int MAXS>
 static int launch_mfma(const TiledRules &t, const FwdPlan &p, const float *X, const float *W, const float *bias,

@@ -118,7 +118,20 @@ class Rulebook:
         self.spatial_out = spatial_out
         info = (ctypes.c_int64 * 8)()
         check(lib().sei_rulebook_info(handle, info))
-        self.n_dst, self.n_src, self.K, self.n_rules, self.n_sub, self.n_tiles, _, self.tile_rows = [int(x) for x in info]
+        self.n_dst, self.n_src, self.K = int(info[0]), int(info[1]), int(info[2])
+
+    def stats(self, tile_rows=None):
+        """(n_rules, n_sub, n_tiles, tile_rows) of a built tile size; builds `tile_rows` (default 128) if none is."""
+        info = (ctypes.c_int64 * 8)()
+        check(lib().sei_rulebook_info(self.h, info))
+        if info[7] == 0 or (tile_rows is not None and info[7] != tile_rows):
+            check(lib().sei_rulebook_build(self.h, tile_rows or 128, _stream()))
+            check(lib().sei_rulebook_info(self.h, info))
+        return int(info[3]), int(info[4]), int(info[5]), int(info[7])
+
+    @property
+    def n_rules(self):
+        return self.stats()[0]
 
     def export(self, device):
         start = (ctypes.c_int64 * (self.K + 1))()

@@ -38,11 +38,7 @@ def main():
     rb = t.metadata.subm_rulebook(sp, [3, 3, 3])
     out = conv(t)
     torch.cuda.synchronize()
-    from sparseeventid_amd import _lib
-    import ctypes
-    info = (ctypes.c_int64 * 8)()
-    _lib.lib().sei_rulebook_info(rb.h, info)
-    R = info[3]
+    R = rb.n_rules
     print("level %d spatial %s N=%d R=%d (R/N=%.2f)" % (a.level, sp, n, R, R / n), flush=True)
     if a.stats:
         start, ri, ro = rb.export("cuda")

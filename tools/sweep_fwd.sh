@@ -1,15 +1,15 @@
 #!/bin/bash
-# sweep forward-kernel tilings on the micro-benchmark (kernel experiments)
+# sweep forward-kernel tilings on the micro-benchmark (kernel experiments): SEI_FWD_PLAN="maxs,cs,slj,nOut"
 out=gpurun_out/sweep_fwd.log; : > $out
 run() { l=$1; c=$2; plan=$3
-  if [ "$plan" = default ]; then unset SEI_FWD_PLAN; else export SEI_FWD_PLAN=$plan; fi
+  if [ "$plan" = default ]; then unset SEI_FWD_PLAN; else export SEI_FWD_PLAN=$plan,$c; fi
   echo "== level $l C=$c plan=$plan" >> $out
   timeout -k 5 120 python tools/conv_micro.py --level $l --cin $c --cout $c --events 16 --iters 5 2>&1 | grep -E "fwd:|Error|error" >> $out
 }
 for p in default "4,1,2" "1,1,2"; do run 0 32 $p; done
 for p in default "4,1,2" "1,1,2"; do run 1 64 $p; done
 for p in default "4,1,2" "1,1,2" "2,2,2"; do run 2 96 $p; done
-for p in default "2,1,2" "2,2,2" "4,2,2" "1,1,2"; do run 3 128 $p; done
-for p in default "2,2,2" "1,1,2"; do run 4 160 $p; done
-for p in default "2,2,2" "1,1,2"; do run 5 192 $p; done
-cat $out
+for p in default "2,1,2" "2,2,2" "4,2,2"; do run 3 128 $p; done
+for p in default "2,2,2" "2,2,1"; do run 4 160 $p; done
+for p in default "2,2,2" "2,2,1"; do run 5 192 $p; done
+grep -A1 "==" $out | paste - - | awk '{print $3,$4,$5,$7,$8,$9,$10}'
