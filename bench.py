@@ -45,13 +45,15 @@ def generate_batch(rank, batch_index, batch, grid, nvox, kind, workers):
     return arr, labels
 
 
-def cpu_baseline(arr, labels, image_size, n_events, fwd_only):
+def cpu_baseline(arr, labels, image_size, n_events, fwd_only, threads=16):
     """Time the CPU oracle (port of the SCN-CPU algorithm; the SCN binary is unavailable) on the first
     `n_events` events of the same batch: forward+backward (or forward only).  Checker code, timed
     here ONLY as the reported baseline."""
     import torch
     from oracle import scn_cpu
     from sparseeventid_amd.data import larcvsparse_to_scnsparse_3d
+    # a one-GPU box owns a 16-core CPU share; more torch threads than that only oversubscribes
+    torch.set_num_threads(max(1, min(threads, os.cpu_count() or 1)))
     heads = {"labelneutID": 3, "labelprotID": 3, "labelnpiID": 2, "labelcpiID": 2}
     cfg = scn_cpu.NetConfig()
     sd = scn_cpu.init_params(cfg, seed=0, heads=heads)
@@ -84,6 +86,7 @@ def main():
     ap.add_argument("--kind", default="tracks", choices=["tracks", "uniform"])
     ap.add_argument("--mode", default="train", choices=["train", "fwd"])
     ap.add_argument("--cpu-events", type=int, default=4, help="events in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=16, help="torch threads of the CPU-baseline leg")
     ap.add_argument("--no-prof", action="store_true", help="skip HIP-event timing of the conv kernels")
     args = ap.parse_args()
 
@@ -170,7 +173,8 @@ def main():
                         "per_kind_per_step": {k: {kk: vv / args.steps for kk, vv in v.items()} for k, v in kinds.items()}}
         cpu = None
         if world == 1 and args.cpu_events > 0:
-            cpu = cpu_baseline(arr, labels, image_size, min(args.cpu_events, args.batch), args.mode == "fwd")
+            cpu = cpu_baseline(arr, labels, image_size, min(args.cpu_events, args.batch), args.mode == "fwd",
+                               args.cpu_threads)
         out = {
             "metric": "events/sec (fwd+bwd) DUNE-3D sparse ResNet, 64-event batch, 1/2/4/8 MI355X"
                       if args.mode == "train" else "events/sec (fwd only) DUNE-3D sparse ResNet",

@@ -1,0 +1,54 @@
+"""CPU: the C-ABI library loads and exports every symbol include/*.h declares (no compute calls)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "sparseeventid_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sei_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_entry_points():
+    names = _declared()
+    assert len(names) >= 30
+    for must in ("sei_input_build", "sei_subm_rulebook", "sei_conv_rulebook", "sei_conv_forward",
+                 "sei_conv_backward_input", "sei_conv_backward_weight", "sei_bn_forward", "sei_bn_backward",
+                 "sei_sparse_to_dense_forward"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol():
+    from sparseeventid_amd import _lib
+    assert os.path.exists(_lib.LIB_PATH), "run `python -c 'import __graft_entry__ as g; g.build()'` first"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in _declared():
+        assert hasattr(lib, name), "library does not export " + name
+    # the python binding binds exactly the header's functions
+    assert sorted(_lib.EXPORTED_SYMBOLS) == _declared()
+    assert _lib.lib().sei_abi_version() == 1
+
+
+def test_product_path_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import sparseeventid_amd.scn as scn
+    with pytest.raises(RuntimeError):
+        scn.InputLayer(3, [8, 8, 8])((torch.zeros(1, 4), torch.ones(1, 1), 1))
+    with pytest.raises(RuntimeError):
+        scn.Metadata()
+
+
+def test_product_code_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "sparseeventid_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src, "%s references the oracle" % f

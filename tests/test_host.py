@@ -1,0 +1,81 @@
+"""CPU: host logic -- transforms against the reference-generated golden vectors, the oracle against its
+own committed fixture, synthetic generator, LR schedule, network construction (state_dict contract)."""
+import math
+import os
+
+import numpy as np
+import torch
+
+from oracle import scn_cpu
+from sparseeventid_amd import data
+from tests.util import rel_err
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+HEADS = {"labelneutID": 3, "labelprotID": 3, "labelnpiID": 2, "labelcpiID": 2}
+
+
+def test_transform_3d_matches_reference_golden():
+    g = np.load(os.path.join(GOLD, "transform_3d.npz"))
+    c, f, b = data.larcvsparse_to_scnsparse_3d(g["input"])
+    assert c.dtype == g["coords"].dtype == np.float64 and f.dtype == g["features"].dtype == np.float32
+    assert np.array_equal(c, g["coords"]) and np.array_equal(f, g["features"]) and b == int(g["batch_size"])
+    assert c.shape == (58, 4) and set(c[:, 3].astype(int)) == {0, 1, 3}   # event 2 is empty
+
+
+def test_transform_2d_matches_reference_golden():
+    g = np.load(os.path.join(GOLD, "transform_2d.npz"))
+    c, f, b = data.larcvsparse_to_scnsparse_2d(g["input"])
+    assert np.array_equal(c, g["coords"]) and np.array_equal(f, g["features"]) and b == int(g["batch_size"])
+    assert c.dtype == np.float64 and np.all(np.diff(c[:, 0]) >= 0)          # plane-major
+
+
+def test_oracle_reproduces_its_golden_fixture():
+    g = np.load(os.path.join(GOLD, "encoder_tiny.npz"))
+    cfg = scn_cpu.NetConfig(depth=2, n_initial_filters=16, n_output_filters=16, blocks_per_layer=1)
+    sd = {k[len("param_"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("param_")}
+    dense = scn_cpu.encoder_forward(sd, cfg, (g["coords"], torch.from_numpy(g["features"]), 2), [1, 32, 32, 32])
+    logits = scn_cpu.head_forward(sd, dense, HEADS)
+    assert rel_err(dense, g["dense"]) < 1e-5
+    for k in HEADS:
+        assert rel_err(logits[k], g["logits_" + k]) < 1e-5
+    loss = scn_cpu.focal_loss(logits, {k: torch.from_numpy(g["label_" + k]) for k in HEADS})
+    assert abs(float(loss) - float(g["loss"])) < 1e-5
+
+
+def test_synthetic_event_contract():
+    ev = data.synthetic_event(123, (900, 900, 900), 50000)
+    assert ev.shape == (50000, 4) and ev.dtype == np.float32
+    xyz = ev[:, :3].astype(np.int64)
+    assert xyz.min() >= 0 and xyz.max() < 900
+    assert len(np.unique(xyz, axis=0)) == 50000                      # exactly 50k distinct voxels
+    assert np.array_equal(ev, data.synthetic_event(123, (900, 900, 900), 50000))   # seeded
+    u = data.uniform_event(5, (64, 64, 64), 1000)
+    assert len(np.unique(u[:, :3], axis=0)) == 1000
+    arr, labels = data.synthetic_dune3d_batch(0, 0, batch_size=2, n_voxels=2000, grid=(128, 128, 128))
+    assert arr.shape == (2, 1, 2000, 4) and set(labels) == set(HEADS)
+    c, f, b = data.larcvsparse_to_scnsparse_3d(arr)
+    assert c.shape == (4000, 4) and b == 2
+
+
+def test_lr_schedule_matches_reference_formula():
+    from sparseeventid_amd.train import WarmupFlatDecay
+    s = WarmupFlatDecay(peak_learning_rate=3e-3, decay_floor=1e-3, epoch_length=10, decay_epochs=5, total_epochs=25)
+    assert abs(s[0] - 1e-5) < 1e-12 and abs(s[5] - (1e-5 + 5 * (3e-3 - 1e-5) / 10)) < 1e-12
+    assert s[10] == 3e-3 and s[199] == 3e-3                        # flat: (25-5-1)*10 steps
+    assert abs(s[200 + 7] - ((3e-3 - 1e-3) * math.exp(-0.07) + 1e-3)) < 1e-12
+    assert s[250] == 0.0
+
+
+def test_network_state_dict_contract():
+    from sparseeventid_amd import build_networks
+    from sparseeventid_amd.config import IMAGE_SIZE, OUTPUT_SHAPE, Config
+    enc, head = build_networks(Config(), IMAGE_SIZE["dune3d"], OUTPUT_SHAPE)
+    sd = enc.state_dict()
+    shapes = scn_cpu.param_shapes(scn_cpu.NetConfig())
+    assert set(sd) == set(shapes) and all(tuple(sd[k].shape) == tuple(shapes[k]) for k in shapes)
+    n = sum(p.numel() for p in enc.parameters()) + sum(p.numel() for p in head.parameters())
+    assert n == 20881994
+    assert enc.output_shape == [128, 32, 16, 40]
+    assert "classification_head.labelneutID.2.weight" in head.state_dict()
+    enc2, _ = build_networks(Config(), IMAGE_SIZE["dune3d_900"], OUTPUT_SHAPE)
+    assert enc2.output_shape == [128, 28, 28, 28]
