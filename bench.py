@@ -85,7 +85,7 @@ def main():
     ap.add_argument("--grid", type=int, nargs=3, default=[900, 900, 900])
     ap.add_argument("--kind", default="tracks", choices=["tracks", "uniform"])
     ap.add_argument("--mode", default="train", choices=["train", "fwd"])
-    ap.add_argument("--cpu-events", type=int, default=4, help="events in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-events", type=int, default=8, help="events in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="torch threads of the CPU-baseline leg")
     ap.add_argument("--no-prof", action="store_true", help="skip HIP-event timing of the conv kernels")
     args = ap.parse_args()
