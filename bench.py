@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--mode", default="train", choices=["train", "fwd"])
     ap.add_argument("--cpu-events", type=int, default=8, help="events in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="torch threads of the CPU-baseline leg")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--no-prof", action="store_true", help="skip HIP-event timing of the conv kernels")
     args = ap.parse_args()
 
@@ -111,8 +113,12 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
+    if args.one_device:
+        local = 0
     torch.cuda.set_device(local)
-    init_from_env("nccl" if world > 1 else None)
+    if world > 1:
+        os.environ["LOCAL_RANK"] = str(local)
+    init_from_env(args.backend if world > 1 else None)
     image_size = [1] + list(grid)
     tr = Trainer(image_size=image_size, device="cuda", seed=0)
     tr.arena.broadcast_parameters()

@@ -164,12 +164,16 @@ template <int MT, int NT>
 __global__ __launch_bounds__(256) void conv_dw_mfma_kernel(
     const float *__restrict__ X, const float *__restrict__ dY, const int32_t *__restrict__ tile_sub_start,
     const int32_t *__restrict__ seg_start, const int32_t *__restrict__ sub_src, const uint8_t *__restrict__ sub_dst,
-    int n_tiles, int TR, int CIN, int COUT, int tiles_per_split, int S, float *__restrict__ slab) {
+    int n_tiles, int TR, int CIN, int COUT, int tiles_per_split, int S, int K, float *__restrict__ slab) {
     extern __shared__ float lds_f[];
     __shared__ int list_sub[DW_LIST_CAP];
     __shared__ int list_tile[DW_LIST_CAP];
     __shared__ int scan_tmp[8];
-    const int k = blockIdx.x, s = blockIdx.y, cig = blockIdx.z;
+    // linear id -> (xcd, k, split group): the K workgroups that walk the same tile range (and re-read the
+    // same dY / X rows) get ids that differ by 8, i.e. run on ONE XCD and share its L2 (speed only)
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int k = j % K, s = (j / K) * 8 + xcd, cig = blockIdx.z;
+    if (s >= S) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r16 = lane & 15, g = lane >> 4;
     const int ci0 = cig * MT * 16;
@@ -341,9 +345,10 @@ static int launch_dw(const TiledRules &t, const float *X, const float *dY, int n
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         attr_set = true;
     }
-    dim3 grid(t.K, S, nIn / (16 * MT));
+    // x = 8 * K * ceil(S/8) linear ids (decoded in the kernel), y = K (carries K only), z = ci blocks
+    dim3 grid(8 * t.K * ((S + 7) / 8), 1, nIn / (16 * MT));
     conv_dw_mfma_kernel<MT, NT><<<grid, 256, lds_bytes, st>>>(X, dY, t.tile_sub_start, t.seg_start, t.sub_src, t.sub_dst,
-                                                              t.n_tiles, t.tile_rows, nIn, nOut, tps, S, slab);
+                                                              t.n_tiles, t.tile_rows, nIn, nOut, tps, S, t.K, slab);
     SEI_LAUNCH_CHECK();
     return 0;
 }
@@ -388,13 +393,18 @@ int conv_backward_weight(const TiledRules &t, const float *X, const float *dY, f
         if (!mt) mfma_ok = false;
     }
     bool small = !mfma_ok && nIn <= 4 && (nOut == 16 || nOut == 32 || nOut == 64);
-    // splits: enough workgroups to fill 256 CUs, bounded slab size
-    int S = (t.n_tiles + DW_TILES_PER_ITER - 1) / DW_TILES_PER_ITER;
-    int target = (2048 + t.K - 1) / t.K;
-    if (S > target) S = target;
-    if (S > 64) S = 64;
+    // splits: a split's dY / X rows (re-read by the K workgroups of that split, which share an XCD) should fit
+    // that XCD's 4 MiB L2; bounded slab size; at least enough workgroups to fill 256 CUs
+    int64_t rows_fit = (3ll << 20) / ((int64_t)(nIn + nOut) * 4);
+    int tps = (int)(rows_fit / t.tile_rows);
+    if (tps > DW_TILES_PER_ITER) tps = DW_TILES_PER_ITER;
+    if (tps < 8) tps = 8;
+    int S = (t.n_tiles + tps - 1) / tps;
+    int64_t smax = (512ll << 20) / ((int64_t)t.K * per * 4);
+    if (smax < 1) smax = 1;
+    if (S > smax) S = (int)smax;
     if (S < 1) S = 1;
-    int tps = (t.n_tiles + S - 1) / S;
+    tps = (t.n_tiles + S - 1) / S;
     S = (t.n_tiles + tps - 1) / tps;
     float *slab;
     SEI_TRY(pool_alloc_t(&slab, (size_t)t.K * S * per));

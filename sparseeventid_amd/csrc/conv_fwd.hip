@@ -115,7 +115,7 @@ template <int NT, int CS, int SLJ, int MAXS>
 __global__ __launch_bounds__(256, occ_for(MAXS, NT, SLJ)) void conv_tile_mfma_kernel(
     const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ Y,
     const int32_t *__restrict__ tile_sub_start, const int32_t *__restrict__ tile_seg,
-    const int32_t *__restrict__ sub_src, const uint8_t *__restrict__ sub_dst, int64_t n_dst, int K, int CIN) {
+    const int32_t *__restrict__ sub_src, const uint8_t *__restrict__ sub_dst, int64_t n_dst, int K, int CIN, int n_tiles) {
     extern __shared__ float lds[];
     constexpr int U = 4 / CS;  // units (groups of CS waves) dealing sub-chunks
     constexpr int TR = 16 * MAXS * U;
@@ -124,7 +124,11 @@ __global__ __launch_bounds__(256, occ_for(MAXS, NT, SLJ)) void conv_tile_mfma_ke
     constexpr int COUT = NC * CS;
     constexpr int PIECES = SL * COUT / 256;  // 1-KiB LDS-DMA pieces per weight slice (contiguous in W)
     constexpr int ASTRIDE = COUT + APAD;     // accumulator row stride (floats)
-    const int tile = blockIdx.x;
+    // workgroups are dealt round-robin to the 8 XCDs: give every XCD one contiguous run of tiles so that
+    // neighbouring tiles (which gather many of the same src rows) share that XCD's L2 (speed only)
+    const int per_xcd = (n_tiles + 7) >> 3;
+    const int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (tile >= n_tiles) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int unit = wave / CS, cg = wave - unit * CS;
     const int col0 = cg * NC;
@@ -385,8 +389,8 @@ static int launch_mfma(const TiledRules &t, const FwdPlan &p, const float *X, co
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    conv_tile_mfma_kernel<NT, CS, SLJ, MAXS><<<t.n_tiles, 256, p.lds_bytes, st>>>(
-        X, W, bias, Y, t.tile_sub_start, t.tile_seg, t.sub_src, t.sub_dst, t.n_dst, t.K, nIn);
+    conv_tile_mfma_kernel<NT, CS, SLJ, MAXS><<<((t.n_tiles + 7) / 8) * 8, 256, p.lds_bytes, st>>>(
+        X, W, bias, Y, t.tile_sub_start, t.tile_seg, t.sub_src, t.sub_dst, t.n_dst, t.K, nIn, t.n_tiles);
     SEI_LAUNCH_CHECK();
     return 0;
 }
