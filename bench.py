@@ -25,8 +25,10 @@ import numpy as np  # noqa: E402
 
 
 def _gen_event(args):
-    from sparseeventid_amd.data import synthetic_event, uniform_event
+    from sparseeventid_amd.data import synthetic_event, synthetic_sbnd_event, uniform_event
     seed, grid, nvox, kind = args
+    if kind == "sbnd":
+        return synthetic_sbnd_event(seed, 3, (grid[1], grid[2]), nvox)
     return (synthetic_event if kind == "tracks" else uniform_event)(seed, grid, nvox)
 
 
@@ -38,7 +40,7 @@ def generate_batch(rank, batch_index, batch, grid, nvox, kind, workers):
             evs = pool.map(_gen_event, jobs)
     else:
         evs = [_gen_event(j) for j in jobs]
-    arr = np.stack(evs)[:, None]
+    arr = np.stack(evs) if kind == "sbnd" else np.stack(evs)[:, None]
     rng = np.random.default_rng(7 + 1000003 * rank + batch_index)
     names = ("labelneutID", "labelprotID", "labelnpiID", "labelcpiID")
     labels = {k: rng.integers(0, n, batch).astype(np.int64) for k, n in zip(names, (3, 3, 2, 2))}
@@ -85,6 +87,8 @@ def main():
     ap.add_argument("--grid", type=int, nargs=3, default=[900, 900, 900])
     ap.add_argument("--kind", default="tracks", choices=["tracks", "uniform"])
     ap.add_argument("--mode", default="train", choices=["train", "fwd"])
+    ap.add_argument("--model", default="dune3d", choices=["dune3d", "sbnd"],
+                    help="dune3d = BASELINE configs[1-3] (headline); sbnd = configs[4] 2-D multiplane shared-weight ResNet")
     ap.add_argument("--cpu-events", type=int, default=8, help="events in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="torch threads of the CPU-baseline leg")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for rehearsals)")
@@ -103,6 +107,10 @@ def main():
     workers = int(os.environ.get("SEI_GEN_WORKERS", "0")) or max(1, min(16, ncpu // max(world, 1)))
     # (under `rocprofv3 --pmc` the GPU is initialised before python starts: set SEI_GEN_WORKERS=1, no fork)
     grid = tuple(args.grid)
+    if args.model == "sbnd":
+        grid, args.kind = (3, 2048, 1280), "sbnd"
+        if args.voxels == 50000:
+            args.voxels = 15000
     arr, labels = generate_batch(rank, 0, args.batch, grid, args.voxels, args.kind, workers)
 
     import torch
@@ -120,7 +128,7 @@ def main():
         os.environ["LOCAL_RANK"] = str(local)
     init_from_env(args.backend if world > 1 else None)
     image_size = [1] + list(grid)
-    tr = Trainer(image_size=image_size, device="cuda", seed=0)
+    tr = Trainer(image_size=image_size, device="cuda", seed=0, model="sbnd" if args.model == "sbnd" else "resnet")
     tr.arena.broadcast_parameters()
     image, lab = tr.stage(tr.to_scn_input(arr), labels)   # inputs resident in HBM before timing
 
@@ -178,18 +186,23 @@ def main():
                         "launches_per_step": tot_n / args.steps, "avg_launch_ms": tot_ms / max(tot_n, 1),
                         "per_kind_per_step": {k: {kk: vv / args.steps for kk, vv in v.items()} for k, v in kinds.items()}}
         cpu = None
-        if world == 1 and args.cpu_events > 0:
+        if world == 1 and args.cpu_events > 0 and args.model == "dune3d":
             cpu = cpu_baseline(arr, labels, image_size, min(args.cpu_events, args.batch), args.mode == "fwd",
                                args.cpu_threads)
         out = {
-            "metric": "events/sec (fwd+bwd) DUNE-3D sparse ResNet, 64-event batch, 1/2/4/8 MI355X"
-                      if args.mode == "train" else "events/sec (fwd only) DUNE-3D sparse ResNet",
+            "metric": ("events/sec (fwd+bwd) DUNE-3D sparse ResNet, 64-event batch, 1/2/4/8 MI355X"
+                       if args.mode == "train" else "events/sec (fwd only) DUNE-3D sparse ResNet")
+                      if args.model == "dune3d" else "events/sec (%s) SBND 2-D multiplane sparse ResNet"
+                      % ("fwd+bwd" if args.mode == "train" else "fwd only"),
             "value": args.batch * world / (ms * 1e-3), "unit": "events/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "dune3d sparse ResNet (depth 5, 32 filters, 4 res-blocks/level) %s, "
-                                   "%d events/GPU x %d voxels in %dx%dx%d, %s generator"
-                                   % ("fwd+bwd+Adam" if args.mode == "train" else "fwd", args.batch, args.voxels,
+            "config": {"workload": "%s %s, %d events/GPU x %d voxels in %dx%dx%d, %s generator"
+                                   % ("dune3d sparse ResNet (depth 5, 32 filters, 4 res-blocks/level)"
+                                      if args.model == "dune3d" else
+                                      "sbnd 2-D multiplane shared-weight sparse ResNet (depth 6, pre-merge 3, 32 filters, "
+                                      "2 res-blocks/level; voxels = pixels per plane)",
+                                      "fwd+bwd+Adam" if args.mode == "train" else "fwd", args.batch, args.voxels,
                                       grid[0], grid[1], grid[2], args.kind),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world},
             "roofline": roof, "cpu_baseline": cpu,

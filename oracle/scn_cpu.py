@@ -407,3 +407,107 @@ def focal_loss(logits, labels):
         l = -y * torch.log(sm) * (1 - sm) ** 2
         loss = loss + l.sum(-1).mean()
     return loss
+
+
+# ----------------------------------------------------------------------------- SBND multiplane network
+class SBNDConfig:
+    """Hyper-parameters of the legacy SBND model; the reference defines none."""
+
+    def __init__(self, n_initial_filters=32, res_blocks_per_layer=2, network_depth=6, depth_pre_merge=3,
+                 spatial_size=(3, 2048, 1280)):
+        self.n_initial_filters = n_initial_filters
+        self.res_blocks_per_layer = res_blocks_per_layer
+        self.network_depth = network_depth
+        self.depth_pre_merge = depth_pre_merge
+        self.spatial_size = list(spatial_size)
+
+
+def sbnd_param_shapes(cfg, output_shape):
+    """state_dict keys/shapes of src/networks/torch/sparseresnet.py:194-302 (batch_norm, leaky_relu on)."""
+    shapes = {"initial_convolution.weight": (25, 1, cfg.n_initial_filters)}
+    nf = cfg.n_initial_filters
+
+    def series(prefix, c, nplanes):
+        k = nplanes * 9
+        for j in range(cfg.res_blocks_per_layer):
+            p = "%s.block_%d" % (prefix, j)
+            for cv, bn in (("conv1", "bn1"), ("conv2", "bn2")):
+                shapes["%s.%s.weight" % (p, cv)] = (k, c, c)
+                for nm in ("weight", "bias", "running_mean", "running_var"):
+                    shapes["%s.%s.%s" % (p, bn, nm)] = (c,)
+
+    def down(prefix, c, co):
+        shapes[prefix + ".conv.weight"] = (4, c, co)
+        for nm in ("weight", "bias", "running_mean", "running_var"):
+            shapes["%s.bn.%s" % (prefix, nm)] = (co,)
+
+    for l in range(cfg.depth_pre_merge):
+        series("pre_convolutional_layers.%d" % (2 * l), nf, 1)
+        down("pre_convolutional_layers.%d" % (2 * l + 1), nf, nf + cfg.n_initial_filters)
+        nf += cfg.n_initial_filters
+    for l in range(cfg.network_depth - cfg.depth_pre_merge):
+        series("post_convolutional_layers.%d" % (2 * l), nf, 3)
+        down("post_convolutional_layers.%d" % (2 * l + 1), nf, nf + cfg.n_initial_filters)
+        nf += cfg.n_initial_filters
+    for key, n_out in output_shape.items():
+        series("final_layer.%s.0" % key, nf, 3)
+        shapes["final_layer.%s.1.weight" % key] = (1, nf, n_out)
+    return shapes
+
+
+def sbnd_init_params(cfg, output_shape, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for k, s in sbnd_param_shapes(cfg, output_shape).items():
+        if k.endswith("running_mean"):
+            sd[k] = torch.zeros(s)
+        elif k.endswith("running_var"):
+            sd[k] = torch.ones(s)
+        elif len(s) == 1:
+            sd[k] = torch.ones(s) if k.endswith(".weight") else torch.zeros(s)
+        else:
+            sd[k] = torch.randn(s, generator=g) * math.sqrt(2.0 / (s[1] * s[0]))
+    return sd
+
+
+def _sbnd_series(t, sd, prefix, cfg, nplanes, training):
+    """SparseBlockSeries of SparseResidualBlocks (sparseresnet.py:47-103,139-158)."""
+    fs = [nplanes, 3, 3]
+    for j in range(cfg.res_blocks_per_layer):
+        p = "%s.block_%d" % (prefix, j)
+        res = t
+        out = subm_conv(t, sd[p + ".conv1.weight"], None, fs)
+        out = batchnorm(out, sd[p + ".bn1.weight"], sd[p + ".bn1.bias"], sd[p + ".bn1.running_mean"],
+                        sd[p + ".bn1.running_var"], training=training, leakiness=0.333)   # BatchNormLeakyReLU
+        out = subm_conv(out, sd[p + ".conv2.weight"], None, fs)
+        out = batchnorm(out, sd[p + ".bn2.weight"], sd[p + ".bn2.bias"], sd[p + ".bn2.running_mean"],
+                        sd[p + ".bn2.running_var"], training=training)
+        t = leaky_relu(add_table([out, res]))
+    return t
+
+
+def _sbnd_down(t, sd, p, training):
+    """SparseConvolutionDownsample (sparseresnet.py:108-137): [1,2,2]/[1,2,2] conv -> BN -> LeakyReLU."""
+    t = strided_conv(t, sd[p + ".conv.weight"], None, [1, 2, 2], [1, 2, 2])
+    t = batchnorm(t, sd[p + ".bn.weight"], sd[p + ".bn.bias"], sd[p + ".bn.running_mean"], sd[p + ".bn.running_var"],
+                  training=training)
+    return leaky_relu(t)
+
+
+def sbnd_forward(sd, cfg, x, output_shape, training=True, mode=3):
+    """ResNet.forward (sparseresnet.py:304-334): returns {key: [B, n_out]}."""
+    coords, features, batch_size = x
+    t = input_layer(coords, features, batch_size, cfg.spatial_size, mode)
+    t = subm_conv(t, sd["initial_convolution.weight"], None, [1, 5, 5])
+    for l in range(cfg.depth_pre_merge):
+        t = _sbnd_series(t, sd, "pre_convolutional_layers.%d" % (2 * l), cfg, 1, training)
+        t = _sbnd_down(t, sd, "pre_convolutional_layers.%d" % (2 * l + 1), training)
+    for l in range(cfg.network_depth - cfg.depth_pre_merge):
+        t = _sbnd_series(t, sd, "post_convolutional_layers.%d" % (2 * l), cfg, 3, training)
+        t = _sbnd_down(t, sd, "post_convolutional_layers.%d" % (2 * l + 1), training)
+    out = {}
+    for key, n_out in output_shape.items():
+        u = _sbnd_series(t, sd, "final_layer.%s.0" % key, cfg, 3, training)
+        u = subm_conv(u, sd["final_layer.%s.1.weight" % key], None, [1, 1, 1])
+        out[key] = sparse_to_dense(u, n_out).mean(dim=(2, 3, 4))
+    return out

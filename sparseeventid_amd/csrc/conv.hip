@@ -363,6 +363,7 @@ static int dispatch_dw(int mt, int nt, const TiledRules &t, const float *X, cons
     DW_CASE(3, 1) DW_CASE(3, 2) DW_CASE(3, 3) DW_CASE(3, 4) DW_CASE(3, 5) DW_CASE(3, 6) DW_CASE(3, 8) DW_CASE(3, 10) DW_CASE(3, 12)
     DW_CASE(4, 1) DW_CASE(4, 2) DW_CASE(4, 3) DW_CASE(4, 4) DW_CASE(4, 5) DW_CASE(4, 6) DW_CASE(4, 8) DW_CASE(4, 10) DW_CASE(4, 12)
     DW_CASE(6, 6) DW_CASE(6, 8) DW_CASE(5, 10) DW_CASE(5, 12) DW_CASE(8, 8)
+    DW_CASE(1, 14) DW_CASE(2, 14) DW_CASE(1, 16) DW_CASE(2, 16) DW_CASE(1, 7) DW_CASE(2, 7) DW_CASE(1, 9) DW_CASE(1, 11) DW_CASE(1, 13) DW_CASE(1, 15)
     SEI_FAIL("conv dW: no MFMA instantiation");
 }
 
@@ -375,14 +376,15 @@ int conv_backward_weight(const TiledRules &t, const float *X, const float *dY, f
     }
     int nt = nOut / 16;
     bool mfma_ok = (nIn % 16 == 0) && (nOut % 16 == 0) &&
-                   (nt == 1 || nt == 2 || nt == 3 || nt == 4 || nt == 5 || nt == 6 || nt == 8 || nt == 10 || nt == 12);
+                   nt >= 1 && nt <= 16;
     int mt = 0;
     if (mfma_ok) {
         int ct = nIn / 16;
         // widest ci block whose accumulators fit (<= 64 16x16 tiles = 256 registers)
         const int cands[] = {8, 6, 5, 4, 3, 2, 1};
         for (int cand : cands) {
-            bool inst = cand <= 4 ? (cand * nt <= 48) :
+            bool inst = cand <= 4 ? (cand * nt <= 48 && (nt <= 6 || nt == 8 || nt == 10 || nt == 12 || cand == 1 ||
+                                                          (cand == 2 && (nt == 7 || nt == 14 || nt == 16)))) :
                         ((cand == 6 && (nt == 6 || nt == 8)) || (cand == 5 && (nt == 10 || nt == 12)) ||
                          (cand == 8 && nt == 8));
             if (ct % cand == 0 && inst) {

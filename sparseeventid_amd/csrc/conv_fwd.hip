@@ -339,7 +339,7 @@ static bool env_plan(int nOut, int *maxs, int *cs, int *slj) {
 
 static FwdPlan plan_forward(int nIn, int nOut, int K) {
     FwdPlan p{};
-    p.mfma = (nIn % 16 == 0) && (nOut % 16 == 0) && nIn >= 16 && nOut <= 192;
+    p.mfma = (nIn % 16 == 0) && (nOut % 16 == 0) && nIn >= 16 && nOut <= 256;
     if (p.mfma) {
         // the tile size depends on nOut only (the rulebook variant is chosen from it)
         if (nOut <= 96) {
@@ -416,12 +416,12 @@ int conv_forward(const TiledRules &t, const float *X, const float *W, const floa
         FWD_BOTH_SLJ(1, 1, 2) FWD_BOTH_SLJ(2, 1, 2) FWD_BOTH_SLJ(3, 1, 2) FWD_BOTH_SLJ(4, 1, 2) FWD_BOTH_SLJ(5, 1, 2)
         FWD_BOTH_SLJ(6, 1, 2)
         FWD_BOTH_SLJ(7, 1, 1) FWD_BOTH_SLJ(8, 1, 1) FWD_BOTH_SLJ(9, 1, 1) FWD_BOTH_SLJ(10, 1, 1) FWD_BOTH_SLJ(11, 1, 1)
-        FWD_BOTH_SLJ(12, 1, 1)
+        FWD_BOTH_SLJ(12, 1, 1) FWD_BOTH_SLJ(13, 1, 1) FWD_BOTH_SLJ(14, 1, 1) FWD_BOTH_SLJ(15, 1, 1) FWD_BOTH_SLJ(16, 1, 1)
         // alternates reachable through SEI_FWD_PLAN (kernel experiments)
         FWD_CASE(2, 1, 2, 4) FWD_CASE(4, 1, 2, 4) FWD_CASE(6, 1, 2, 4)
         FWD_CASE(2, 1, 2, 1) FWD_CASE(4, 1, 2, 1) FWD_CASE(6, 1, 2, 1)
         FWD_CASE(4, 2, 2, 2) FWD_CASE(5, 2, 2, 2) FWD_CASE(6, 2, 2, 2) FWD_CASE(3, 2, 2, 2)
-        FWD_CASE(4, 2, 2, 4) FWD_CASE(5, 2, 2, 4) FWD_CASE(6, 2, 2, 4)
+        FWD_CASE(4, 2, 2, 4) FWD_CASE(5, 2, 2, 4) FWD_CASE(6, 2, 2, 4) FWD_CASE(3, 2, 2, 4) FWD_CASE(2, 2, 2, 4) FWD_CASE(1, 2, 2, 4)
         FWD_CASE(8, 1, 2, 2) FWD_CASE(4, 2, 1, 2) FWD_CASE(5, 2, 1, 2) FWD_CASE(6, 2, 1, 2)
         SEI_FAIL("conv_forward: no MFMA instantiation for this plan");
     }

@@ -115,3 +115,32 @@ def synthetic_dune3d_batch(rank, batch_index, batch_size=64, grid=(900, 900, 900
     names = ("labelneutID", "labelprotID", "labelnpiID", "labelcpiID")
     labels = {k: rng.integers(0, n, batch_size).astype(np.int64) for k, n in zip(names, n_classes)}
     return arr, labels
+
+
+def synthetic_sbnd_event(seed, planes=3, hw=(2048, 1280), n_pix=15000):
+    """One SBND-like event: per wire plane a 2-D projection of tracks + blobs, exactly ``n_pix`` distinct
+    pixels; larcv 2-D layout [planes, n_pix, 3] = (x, y, value) (larcv_scripts/preprocess_fullres_2D.cfg)."""
+    rng = np.random.default_rng(seed)
+    H, W = hw
+    out = np.empty((planes, n_pix, 3), np.float32)
+    vertex = np.array([H, W]) * rng.uniform(0.3, 0.7, 2)
+    for p in range(planes):
+        pts = []
+        for _ in range(int(rng.integers(6, 14))):
+            ang = rng.uniform(0, 2 * np.pi)
+            s = np.arange(0.0, rng.uniform(150, 900), 0.25)
+            pts.append(vertex + s[:, None] * np.array([np.sin(ang), np.cos(ang)]) + rng.normal(0, 0.8, (len(s), 2)))
+        keys = np.empty(0, np.int64)
+        pts = np.concatenate(pts)
+        while True:
+            v = np.clip(np.floor(pts).astype(np.int64), 0, [H - 1, W - 1])
+            keys = np.union1d(keys, v[:, 0] * W + v[:, 1])
+            if len(keys) >= n_pix:
+                break
+            c = vertex + rng.normal(0, 120, 2)
+            pts = c + rng.normal(0, rng.uniform(5, 40), (2 * (n_pix - len(keys)) + 500, 2))
+        keys = np.sort(rng.choice(keys, n_pix, replace=False))
+        out[p, :, 1] = keys // W            # y (row, < 2048)
+        out[p, :, 0] = keys % W             # x (col, < 1280)
+        out[p, :, 2] = (rng.lognormal(0.0, 0.5, n_pix) - 1.0) / 0.5
+    return out

@@ -43,11 +43,23 @@ class Trainer:
     """Owns encoder + heads (reference topology), the flat parameter/gradient arenas and Adam."""
 
     def __init__(self, cfg=None, image_size=None, output_shape=None, weight_decay=1e-6, lr_schedule=None,
-                 device="cuda", seed=0):
+                 device="cuda", seed=0, model="resnet", sbnd_cfg=None):
         self.cfg = cfg or Config()
-        self.image_size = image_size or IMAGE_SIZE["dune3d" if self.cfg.data.dimension == 3 else "dune2d"]
+        self.model = model
         torch.manual_seed(seed)
-        self.encoder, self.head = build_networks(self.cfg, self.image_size, output_shape or OUTPUT_SHAPE)
+        if model == "sbnd":
+            # legacy multiplane network (src/networks/torch/sparseresnet.py): logits come straight out of it
+            from .config import Data
+            from .networks_sbnd import ResNet, SBNDNetworkConfig
+            self.cfg = Config(data=Data(dimension=2))
+            sbnd_cfg = sbnd_cfg or SBNDNetworkConfig()
+            self.image_size = list(sbnd_cfg.spatial_size)
+            shape = output_shape or OUTPUT_SHAPE
+            self.encoder = ResNet({k: [v] for k, v in shape.items()}, sbnd_cfg)
+            self.head = torch.nn.Identity()
+        else:
+            self.image_size = image_size or IMAGE_SIZE["dune3d" if self.cfg.data.dimension == 3 else "dune2d"]
+            self.encoder, self.head = build_networks(self.cfg, self.image_size, output_shape or OUTPUT_SHAPE)
         self.encoder.to(device)
         self.head.to(device)
         self.arena = FlatArena([self.encoder, self.head])

@@ -79,3 +79,12 @@ def test_network_state_dict_contract():
     assert "classification_head.labelneutID.2.weight" in head.state_dict()
     enc2, _ = build_networks(Config(), IMAGE_SIZE["dune3d_900"], OUTPUT_SHAPE)
     assert enc2.output_shape == [128, 28, 28, 28]
+
+
+def test_sbnd_state_dict_contract():
+    from sparseeventid_amd.networks_sbnd import ResNet, SBNDNetworkConfig
+    net = ResNet({"label": [3]}, SBNDNetworkConfig())
+    shapes = scn_cpu.sbnd_param_shapes(scn_cpu.SBNDConfig(), {"label": 3})
+    sd = net.state_dict()
+    assert set(sd) == set(shapes) and all(tuple(sd[k].shape) == tuple(shapes[k]) for k in shapes)
+    assert "pre_convolutional_layers.0.block_0.conv1.weight" in sd and "final_layer.label.1.weight" in sd
