@@ -51,6 +51,13 @@ void sei_metadata_destroy(sei_metadata_t *m);
  * Synchronises `stream` to return *n_rows. */
 int sei_input_build(sei_metadata_t *m, const int32_t *coords_dev, int64_t n, const int32_t spatial[3],
                     int32_t batch_size, int32_t mode, sei_stream_t stream, int64_t *n_rows);
+/* larcv batch -> scn input tuple on the device (src/io/data_transforms.py:21-49 3-D, :198-253 2-D):
+ * larcv_dev fp32 [B,P,M,D+1] with -999 padding (D=3: (x,y,z,value), P=1; D=2: (x,y,value), P planes).
+ * Emits coords int32 [n,4] ((x,y,z,batch) batch-major, or (plane,y,x,batch) plane-major -- the reference's
+ * order) and features [n,1]; outputs must hold B*P*M entries.  Synchronises `stream` to return *n_points. */
+int sei_larcv_to_scn(const float *larcv_dev, int32_t B, int32_t P, int32_t M, int32_t D, int32_t *coords_out_dev,
+                     float *features_out_dev, sei_stream_t stream, int64_t *n_points);
+
 /* InputLayer feature pass: out[n_rows,C] from in[n,C] (SCN `InputLayer_updateOutput`). */
 int sei_input_features_fwd(sei_metadata_t *m, const float *in, int32_t C, float *out, sei_stream_t stream);
 /* ... and its gradient (SCN `InputLayer_updateGradInput`): din[n,C] from dout[n_rows,C]. */

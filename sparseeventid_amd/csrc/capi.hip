@@ -188,6 +188,12 @@ int sei_input_build(sei_metadata_t *m, const int32_t *coords_dev, int64_t n, con
     return build_input_level(m, coords_dev, n, spatial, batch_size, (hipStream_t)stream, n_rows);
 }
 
+int sei_larcv_to_scn(const float *larcv_dev, int32_t B, int32_t P, int32_t M, int32_t D, int32_t *coords_out_dev,
+                     float *features_out_dev, sei_stream_t stream, int64_t *n_points) {
+    if (!larcv_dev || !coords_out_dev || !features_out_dev || !n_points) SEI_FAIL("sei_larcv_to_scn: null argument");
+    return larcv_compact(larcv_dev, B, P, M, D, coords_out_dev, features_out_dev, n_points, (hipStream_t)stream);
+}
+
 int sei_input_features_fwd(sei_metadata_t *m, const float *in, int32_t C, float *out, sei_stream_t stream) {
     if (!m) SEI_FAIL("null metadata");
     return input_features_fwd(m, in, C, out, (hipStream_t)stream);

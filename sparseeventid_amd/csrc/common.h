@@ -145,6 +145,8 @@ int build_input_level(sei_metadata *m, const int32_t *coords, int64_t n, const i
 int input_features_fwd(sei_metadata *m, const float *in, int C, float *out, hipStream_t st);
 int input_features_bwd(sei_metadata *m, const float *dout, int C, float *din, hipStream_t st);
 int exclusive_scan_i32(const int32_t *in, int32_t *out, int64_t n, int32_t *total_dev, hipStream_t st);
+int larcv_compact(const float *in, int B, int P, int M, int D, int32_t *coords, float *feats, int64_t *n_out,
+                  hipStream_t st);
 // rulebook.hip
 inline int variant_of(int tile_rows) { return tile_rows == 256 ? 0 : (tile_rows == 128 ? 1 : 2); }
 // returns the (lazily built) tiled rules of the rulebook: transposed=false -> fwd, true -> bwd

@@ -307,4 +307,65 @@ int input_features_bwd(sei_metadata *m, const float *dout, int C, float *din, hi
     return 0;
 }
 
+// ------------------------------------------------------------------ larcv batch -> scn tuple on the device
+// src/io/data_transforms.py:21-49 (3-D) / :198-253 (2-D): strip the -999 padding of [B,P,M,D+1] and emit
+// coords int32 [N,4] + features [N,1] in the reference's order (3-D: batch-major; 2-D: plane-major).
+// element e of the OUTPUT order = ((p*B + b)*M + v) for 2-D, ((b*P + p)*M + v) for 3-D.
+__global__ void larcv_flag_kernel(const float *__restrict__ in, int B, int P, int M, int D, int plane_major,
+                                  int32_t *flag) {
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t tot = (int64_t)B * P * M;
+    if (e >= tot) return;
+    int v = (int)(e % M);
+    int64_t q = e / M;
+    int b, p;
+    if (plane_major) { p = (int)(q / B); b = (int)(q % B); } else { b = (int)(q / P); p = (int)(q % P); }
+    const float *r = in + (((int64_t)b * P + p) * M + v) * (D + 1);
+    flag[e] = r[D] != -999.f ? 1 : 0;
+}
+
+__global__ void larcv_emit_kernel(const float *__restrict__ in, int B, int P, int M, int D, int plane_major,
+                                  const int32_t *__restrict__ pos, int32_t *__restrict__ coords,
+                                  float *__restrict__ feats) {
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t tot = (int64_t)B * P * M;
+    if (e >= tot) return;
+    int v = (int)(e % M);
+    int64_t q = e / M;
+    int b, p;
+    if (plane_major) { p = (int)(q / B); b = (int)(q % B); } else { b = (int)(q / P); p = (int)(q % P); }
+    const float *r = in + (((int64_t)b * P + p) * M + v) * (D + 1);
+    if (r[D] == -999.f) return;
+    int o = pos[e];
+    int4 c;
+    if (D == 3) c = make_int4((int)r[0], (int)r[1], (int)r[2], b);   // (x, y, z, batch)
+    else        c = make_int4(p, (int)r[1], (int)r[0], b);           // (plane, y, x, batch)
+    reinterpret_cast<int4 *>(coords)[o] = c;
+    feats[o] = r[D];
+}
+
+int larcv_compact(const float *in, int B, int P, int M, int D, int32_t *coords, float *feats, int64_t *n_out,
+                  hipStream_t st) {
+    if (D != 2 && D != 3) SEI_FAIL("larcv_compact: D must be 2 or 3");
+    int64_t tot = (int64_t)B * P * M;
+    if (tot >= (1ll << 31) - 64) SEI_FAIL("larcv_compact: batch too large");
+    if (tot == 0) { *n_out = 0; return 0; }
+    int32_t *flag, *total;
+    SEI_TRY(pool_alloc_t(&flag, tot));
+    SEI_TRY(pool_alloc_t(&total, 2));
+    unsigned nb = (unsigned)((tot + 255) / 256);
+    int pm = D == 2 ? 1 : 0;
+    larcv_flag_kernel<<<nb, 256, 0, st>>>(in, B, P, M, D, pm, flag);
+    SEI_LAUNCH_CHECK();
+    SEI_TRY(exclusive_scan_i32(flag, flag, tot, total, st));
+    larcv_emit_kernel<<<nb, 256, 0, st>>>(in, B, P, M, D, pm, flag, coords, feats);
+    SEI_LAUNCH_CHECK();
+    int32_t host;
+    SEI_HIP(hipMemcpyAsync(&host, total, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    SEI_HIP(hipStreamSynchronize(st));
+    *n_out = host;
+    pool_free(flag); pool_free(total);
+    return 0;
+}
+
 }  // namespace sei

@@ -334,6 +334,22 @@ class _SparseToDense(torch.autograd.Function):
         return dfeat, None, None, None
 
 
+def larcv_to_scn_device(larcv_batch):
+    """Device-side ``larcvsparse_to_scnsparse_3d / _2d`` (src/io/data_transforms.py:21-49,198-253):
+    larcv batch [B,P,M,D+1] (any device; -999 padded) -> (coords int32 [N,4] cuda, features fp32 [N,1] cuda, B),
+    same values and order as the host transform, ready for InputLayer (no float64 host round trip)."""
+    x = torch.as_tensor(larcv_batch)
+    if not torch.cuda.is_available():
+        raise RuntimeError("sparseeventid_amd.larcv_to_scn_device: no MI355X (cuda) device")
+    x = _f32c(x.cuda())
+    B, P, M, D1 = x.shape
+    coords = torch.empty((B * P * M, 4), dtype=torch.int32, device=x.device)
+    feats = torch.empty((B * P * M, 1), dtype=torch.float32, device=x.device)
+    n = ctypes.c_int64()
+    check(lib().sei_larcv_to_scn(_ptr(x), B, P, M, D1 - 1, _ptr(coords), _ptr(feats), _stream(), ctypes.byref(n)))
+    return coords[:n.value], feats[:n.value], B
+
+
 # ============================================================================= functional helpers
 def batchnorm_act(x, bn, leak=1.0, residual=None):
     """Fused BatchNormalization (+AddTable residual) + LeakyReLU on a features tensor."""

@@ -109,3 +109,57 @@ class Trainer:
         if labels is None:
             return logits
         return logits, accuracy(logits, labels)
+
+
+    # ------------------------------------------------------------------ checkpoint / resume
+    # Lightning-layout checkpoints: {"state_dict": {"encoder.*", "head.*"}, "global_step", "optimizer"} --
+    # what ModelCheckpoint writes and what create_trainer.py:93-115 reads back
+    # (/root/reference/src/utils/create_trainer.py:83-115).
+    def state_dict(self):
+        sd = {"encoder." + k: v for k, v in self.encoder.state_dict().items()}
+        sd.update({"head." + k: v for k, v in self.head.state_dict().items()})
+        return sd
+
+    def save_checkpoint(self, path):
+        import os
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        torch.save({"state_dict": {k: v.detach().cpu() for k, v in self.state_dict().items()},
+                    "global_step": self.global_step, "optimizer": self.opt.state_dict()}, path)
+
+    def _load_into(self, module, prefix, state):
+        sub = {k[len(prefix):]: v for k, v in state.items() if k.startswith(prefix)}
+        own = module.state_dict()
+        missing = [k for k in own if k not in sub]
+        if missing:
+            raise KeyError("checkpoint lacks %s%s" % (prefix, missing[0]))
+        with torch.no_grad():                        # copy IN PLACE: parameters are views of the flat arena
+            for k, t in own.items():
+                t.copy_(sub[k].to(t.device))
+
+    def load_checkpoint(self, path, resume=True):
+        """Auto-resume (create_trainer.py:110-115): weights, step counter and optimizer state."""
+        ck = torch.load(path, map_location="cpu")
+        self._load_into(self.encoder, "encoder.", ck["state_dict"])
+        self._load_into(self.head, "head.", ck["state_dict"])
+        if resume:
+            self.global_step = int(ck.get("global_step", 0))
+            if "optimizer" in ck:
+                self.opt.load_state_dict(ck["optimizer"])
+                self.flat_param.grad = self.arena.grad
+
+    def restore_encoder_only(self, path, freeze=True):
+        """mode.weights_location + restore_encoder_only (create_trainer.py:93-106): load the ``encoder.*`` keys
+        and freeze the encoder."""
+        ck = torch.load(path, map_location="cpu")
+        self._load_into(self.encoder, "encoder.", ck["state_dict"])
+        if freeze:
+            for p in self.encoder.parameters():
+                p.requires_grad_(False)
+
+
+def format_log_message(metrics, batch_size, global_step, dt=None, mode=""):
+    """training_utils.format_log_message (src/utils/training_utils.py:31-60): 'key: value' list + Img/s."""
+    s = ", ".join("{0}: {1:.3}".format(k, float(v)) for k, v in metrics.items())
+    if dt is not None and dt > 0:
+        s += " ({:.2}s / {:.2} Img/s)".format(dt, batch_size / dt)
+    return "{} Step {} metrics: {}".format(mode, global_step, s)

@@ -231,3 +231,24 @@ def test_conv_is_deterministic():
         conv.weight.grad = None
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+def test_device_larcv_transform_matches_host_transform():
+    import os
+    scn = _engine()
+    from sparseeventid_amd import data
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    for name, host_fn in (("transform_3d.npz", data.larcvsparse_to_scnsparse_3d),
+                          ("transform_2d.npz", data.larcvsparse_to_scnsparse_2d)):
+        g = np.load(os.path.join(gold, name))
+        c, f, b = scn.larcv_to_scn_device(g["input"])
+        assert b == int(g["batch_size"])
+        assert np.array_equal(c.cpu().numpy().astype(np.float64), g["coords"])      # reference golden, exact
+        assert np.array_equal(f.cpu().numpy(), g["features"])
+        hc, hf, hb = host_fn(g["input"])
+        assert np.array_equal(c.cpu().numpy(), hc.astype(np.int32))
+    # and the tuple feeds InputLayer directly
+    arr, _ = data.synthetic_dune3d_batch(0, 0, batch_size=2, n_voxels=3000, grid=(128, 128, 128))
+    c, f, b = scn.larcv_to_scn_device(arr)
+    t = scn.InputLayer(3, [128, 128, 128])((c, f, b))
+    assert t.features.shape == (6000, 1)
