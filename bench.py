@@ -181,8 +181,17 @@ def main():
                     tot_n += q[0]; tot_ms += q[1]; tot_fl += q[2]
             if tot_ms > 0:
                 ach = tot_fl / (tot_ms * 1e-3) / 1e12
+                # HBM traffic cannot be read live: it comes from the committed PMC passes of this same command
+                traffic = None
+                tpath = os.path.join(ROOT, "profiles", "r01_conv_fwd_hbm_traffic.json")
+                if (os.path.exists(tpath) and args.model == "dune3d" and args.mode == "train" and args.batch == 64
+                        and args.voxels == 50000 and args.kind == "tracks"):
+                    traffic = json.load(open(tpath))["traffic_bytes_per_launch"]
                 roof = {"bound": "mfma", "kernel": "conv_tile_mfma_kernel (fwd + dX launches)", "achieved": ach,
-                        "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3, "traffic": None,
+                        "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3, "traffic": traffic,
+                        "traffic_note": "HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                                        "(profiles/r01_conv_fwd_hbm_traffic.json); algorithmic bytes per launch %.3g"
+                                        % ((kinds["conv_fwd"]["gbyte"] + kinds["conv_bwd_input"]["gbyte"]) * 1e9 / max(tot_n, 1)),
                         "launches_per_step": tot_n / args.steps, "avg_launch_ms": tot_ms / max(tot_n, 1),
                         "per_kind_per_step": {k: {kk: vv / args.steps for kk, vv in v.items()} for k, v in kinds.items()}}
         cpu = None
