@@ -59,18 +59,25 @@ __device__ __forceinline__ void load_b(const float *__restrict__ wrow, int r16, 
 template <int NT, int SLJ, int MS, int MAXS, int COUT>
 __device__ __forceinline__ void compute_phase(const float *__restrict__ wb, const float4 (&a)[MAXS][SLJ],
                                               f32x4 (&acc)[MAXS][NT], int g, int r16) {
+    // B operands are read from LDS one step ahead of the MFMAs that consume them
+    constexpr int STEPS = 4 * SLJ;
+    float b[2][NT];
+    load_b<NT>(wb + (4 * g) * COUT, r16, b[0]);
 #pragma unroll
-    for (int jj = 0; jj < SLJ; jj++) {
+    for (int st = 0; st < STEPS; st++) {
+        const int jj = st >> 2, e = st & 3;
+        if (st + 1 < STEPS) {
+            const int jn = (st + 1) >> 2, en = (st + 1) & 3;
+            load_b<NT>(wb + (16 * jn + 4 * g + en) * COUT, r16, b[(st + 1) & 1]);
+        }
+        // nothing may cross: the next step's LDS reads are ISSUED before this step's MFMAs (hipcc otherwise
+        // sinks them behind the MFMAs and waits lgkmcnt(0) with the matrix pipe idle)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-            float b[NT];
-            load_b<NT>(wb + (16 * jj + 4 * g + e) * COUT, r16, b);
+        for (int m = 0; m < MS; m++) {
+            const float av = e == 0 ? a[m][jj].x : e == 1 ? a[m][jj].y : e == 2 ? a[m][jj].z : a[m][jj].w;
 #pragma unroll
-            for (int m = 0; m < MS; m++) {
-                const float av = e == 0 ? a[m][jj].x : e == 1 ? a[m][jj].y : e == 2 ? a[m][jj].z : a[m][jj].w;
-#pragma unroll
-                for (int n = 0; n < NT; n++) acc[m][n] = mfma16(av, b[n], acc[m][n]);
-            }
+            for (int n = 0; n < NT; n++) acc[m][n] = mfma16(av, b[st & 1][n], acc[m][n]);
         }
     }
 }
@@ -94,9 +101,10 @@ __device__ __forceinline__ void stage_slice(const float *__restrict__ wslice, fl
 
 template <int MAXS>
 struct RuleIdx {
-    int src[MAXS];        // lane r16: src row of rule slot r16 (A operand row)
+    int src[MAXS];        // lane r16: src row of rule slot r16 (A operand row); RAW load, see valid()
     uint32_t d4[MAXS];    // lane group g: packed dst rows (tile-local) of result rows 4g..4g+3
-    int ms;
+    int ms;               // sub-chunks this wave owns for the offset (wave-uniform); slots m >= ms hold junk
+    __device__ __forceinline__ int row(int m) const { return m < ms ? src[m] : -1; }
 };
 
 constexpr int occ_for(int maxs, int nt, int slj) {
@@ -167,10 +175,10 @@ __global__ __launch_bounds__(256, occ_for(MAXS, NT, SLJ)) void conv_tile_mfma_ke
             const int s = unit + m * U;
             const bool valid = s < ns;
             const int64_t sb = (sub0 + s0 + (valid ? s : 0)) * SUB_SLOTS;
-            const int sv = sub_src[sb + r16];
-            const uint32_t dv = *reinterpret_cast<const uint32_t *>(sub_dst + sb + 4 * g);
-            r.src[m] = valid ? sv : -1;
-            r.d4[m] = dv;
+            // the loaded values are NOT touched here: selecting on them would stall this wave for a full
+            // memory latency per offset; validity is applied where they are consumed (2 offsets later)
+            r.src[m] = sub_src[sb + r16];
+            r.d4[m] = *reinterpret_cast<const uint32_t *>(sub_dst + sb + 4 * g);
             if (valid) ms = m + 1;
         }
         r.ms = __builtin_amdgcn_readfirstlane(ms);
@@ -187,19 +195,41 @@ __global__ __launch_bounds__(256, occ_for(MAXS, NT, SLJ)) void conv_tile_mfma_ke
         for (int m = 0; m < MAXS; m++)
 #pragma unroll
             for (int jj = 0; jj < SLJ; jj++) {
-                a_c[m][jj] = load_a(X, ic.src[m], CIN, 16 * jj + 4 * g);
+                a_c[m][jj] = load_a(X, ic.row(m), CIN, 16 * jj + 4 * g);
                 a_n[m][jj] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         int phase = 0;
         while (k < K) {
             const int kw = k1 < K ? k1 : k;  // weights to prefetch after the last slice (unused at the very end)
             f32x4 acc[MAXS][NT];
+            float *prow[MAXS][4];
+            int nv[MAXS];
 #pragma unroll
-            for (int m = 0; m < MAXS; m++)
+            for (int m = 0; m < MAXS; m++) {
+                // padding sits at the end of a sub-chunk: slots [0, nv) are rules
+                nv[m] = __popcll(__ballot(ic.row(m) >= 0) & 0xFFFFull);
 #pragma unroll
-                for (int n = 0; n < NT; n++) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int i = 0; i < 4; i++)
+                    prow[m][i] = acc_tile + ((ic.d4[m] >> (8 * i)) & 0xFF) * ASTRIDE + col0 + r16;
+            }
             for (int s = 0; s < NS; s++) {
                 __syncthreads();  // this phase's slice has landed (vmcnt(0) + barrier); previous phase fully consumed
+                if (s == 0) {
+                    // D[row = 4g+i][col = r16] belongs to rule slot 4g+i.  Rows of one offset are distinct and the
+                    // previous offset's updates are behind the barrier: the accumulators START from the tile's
+                    // current values (plain LDS reads, latency hidden under the loads issued next) and are
+                    // simply written back after the last slice -- no atomics (LDS float atomics cost ~150
+                    // cycles per wave-instruction on gfx950), no separate add, fixed summation order.
+#pragma unroll
+                    for (int m = 0; m < MAXS; m++) {
+                        if (m < ic.ms) {  // wave-uniform: one branch per sub-chunk, loads inside are unconditional
+#pragma unroll
+                            for (int n = 0; n < NT; n++)
+#pragma unroll
+                                for (int i = 0; i < 4; i++) acc[m][n][i] = prow[m][i][16 * n];
+                        }
+                    }
+                }
                 // prefetch the next phase's weight slice and A fragments while this one computes
                 const bool same_k = s + 1 < NS;
                 stage_slice<PIECES>(W + ((size_t)(same_k ? k : kw) * CIN + (size_t)(same_k ? s + 1 : 0) * SL) * COUT,
@@ -209,7 +239,7 @@ __global__ __launch_bounds__(256, occ_for(MAXS, NT, SLJ)) void conv_tile_mfma_ke
                 for (int m = 0; m < MAXS; m++)
 #pragma unroll
                     for (int jj = 0; jj < SLJ; jj++)
-                        a_n[m][jj] = load_a(X, same_k ? ic.src[m] : in1.src[m], CIN, aoff + 16 * jj);
+                        a_n[m][jj] = load_a(X, same_k ? ic.row(m) : in1.row(m), CIN, aoff + 16 * jj);
                 const float *wb = wbuf + (size_t)(phase & 1) * SL * COUT + col0;
                 if (MAXS == 1) {
                     if (ic.ms == 1) compute_phase<NT, SLJ, 1, MAXS, COUT>(wb, a_c, acc, g, r16);
@@ -231,28 +261,14 @@ __global__ __launch_bounds__(256, occ_for(MAXS, NT, SLJ)) void conv_tile_mfma_ke
                     for (int jj = 0; jj < SLJ; jj++) a_c[m][jj] = a_n[m][jj];
                 phase++;
             }
-            // D[row = 4g+i][col = r16] belongs to rule slot 4g+i of the sub-chunk.  Rows of one offset are
-            // distinct and the previous offset's updates are barrier-separated: plain read-modify-write
-            // (LDS float atomics cost ~150 cycles per wave-instruction on gfx950).
 #pragma unroll
             for (int m = 0; m < MAXS; m++) {
                 if (m < ic.ms) {
-                    // padding sits at the end of the sub-chunk: slots [0, nv) are rules
-                    const int nv = __popcll(__ballot(ic.src[m] >= 0) & 0xFFFFull);
-                    float old[4][NT];
-                    float *p[4];
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
-                        const int dd = (ic.d4[m] >> (8 * i)) & 0xFF;
-                        p[i] = acc_tile + dd * ASTRIDE + col0 + r16;
+                        if (4 * g + i < nv[m]) {
 #pragma unroll
-                        for (int n = 0; n < NT; n++) old[i][n] = p[i][16 * n];
-                    }
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        if (4 * g + i < nv) {
-#pragma unroll
-                            for (int n = 0; n < NT; n++) p[i][16 * n] = old[i][n] + acc[m][n][i];
+                            for (int n = 0; n < NT; n++) prow[m][i][16 * n] = acc[m][n][i];
                         }
                     }
                 }
