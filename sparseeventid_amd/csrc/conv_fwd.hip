@@ -374,10 +374,6 @@ static FwdPlan plan_forward(int nIn, int nOut, int K) {
         }
         p.nt = nOut / 16 / p.cs;
         p.tile_rows = 16 * p.maxs * (4 / p.cs);
-        // keep two workgroups per CU when halving the slice allows it
-        if (p.slj == 2 && fwd_lds(p.tile_rows, nOut, 2, K) > 80 * 1024 && fwd_lds(p.tile_rows, nOut, 1, K) <= 80 * 1024 &&
-            !forced)
-            p.slj = 1;
         p.lds_bytes = fwd_lds(p.tile_rows, nOut, p.slj, K);
         if (p.lds_bytes > 160 * 1024) p.mfma = false;
     }
