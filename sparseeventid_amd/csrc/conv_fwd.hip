@@ -213,7 +213,14 @@ __global__ __launch_bounds__(256, occ_for(MAXS, NT, SLJ)) void conv_tile_mfma_ke
                     prow[m][i] = acc_tile + ((ic.d4[m] >> (8 * i)) & 0xFF) * ASTRIDE + col0 + r16;
             }
             for (int s = 0; s < NS; s++) {
-                __syncthreads();  // this phase's slice has landed (vmcnt(0) + barrier); previous phase fully consumed
+                // Barrier: this phase's weight slice (LDS-DMA issued one phase ago) has landed in every wave and the
+                // previous phase is fully consumed.  __syncthreads() would wait vmcnt(0), i.e. also for the index
+                // loads of offset k+2 issued just above -- a full memory latency per offset.  Those 2*MAXS loads are
+                // the youngest in flight (vmcnt retires in order), so leave exactly them outstanding.
+                if (s == 0 && phase > 0)
+                    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * MAXS) : "memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 if (s == 0) {
                     // D[row = 4g+i][col = r16] belongs to rule slot 4g+i.  Rows of one offset are distinct and the
                     // previous offset's updates are behind the barrier: the accumulators START from the tile's
@@ -293,7 +300,65 @@ __global__ __launch_bounds__(256, occ_for(MAXS, NT, SLJ)) void conv_tile_mfma_ke
     }
 }
 
-// Any channel counts (stem Cin=1, odd test sizes): same tile / sub-chunk walk, scalar FMA.
+// Stem-type convolutions (tiny nIn, e.g. 1 -> 32 with 125 offsets): all of W sits in LDS, lane = output
+// plane so that every LDS accumulator access is a contiguous row segment (the generic kernel below strides
+// rows across lanes: 16-way bank conflicts).  HBM / LDS bound, no MFMA (64 flop per rule).
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void conv_tile_smallcin_kernel(
+    const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ Y,
+    const int32_t *__restrict__ tile_sub_start, const int32_t *__restrict__ tile_seg,
+    const int32_t *__restrict__ sub_src, const uint8_t *__restrict__ sub_dst, int64_t n_dst, int K, int TR) {
+    extern __shared__ float lds[];
+    float *acc = lds;                       // [TR][COUT]
+    float *wl = lds + (size_t)TR * COUT;    // [K][CIN][COUT]
+    const int tile = blockIdx.x;
+    for (int idx = threadIdx.x; idx < TR * COUT; idx += 256) acc[idx] = bias ? bias[idx % COUT] : 0.f;
+    for (int idx = threadIdx.x; idx < K * CIN * COUT; idx += 256) wl[idx] = W[idx];
+    __syncthreads();
+    const int64_t sub0 = tile_sub_start[tile];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int groups = 64 / COUT, STEPS = SUB_SLOTS / groups;
+    const int co = lane % COUT, grp = lane / COUT, r16 = lane & 15;
+    const int32_t *seg = tile_seg + (size_t)tile * (K + 1);
+    for (int k = 0; k < K; k++) {
+        const int s0 = seg[k], s1 = seg[k + 1];
+        if (s1 == s0) continue;  // uniform for the workgroup
+        float wk[CIN];
+#pragma unroll
+        for (int ci = 0; ci < CIN; ci++) wk[ci] = wl[(k * CIN + ci) * COUT + co];
+        for (int s = s0 + wave; s < s1; s += 4) {
+            const int64_t sb = (sub0 + s) * SUB_SLOTS;
+            const int src_r = sub_src[sb + r16];
+            const int dst_r = sub_dst[sb + r16];
+            float xv[STEPS][CIN];
+            int dl[STEPS], ok[STEPS];
+#pragma unroll
+            for (int q = 0; q < STEPS; q++) {
+                const int slot = q * groups + grp;
+                const int src = __shfl(src_r, slot);
+                dl[q] = __shfl(dst_r, slot);
+                ok[q] = src >= 0;
+#pragma unroll
+                for (int ci = 0; ci < CIN; ci++) xv[q][ci] = X[(size_t)(src >= 0 ? src : 0) * CIN + ci];
+            }
+#pragma unroll
+            for (int q = 0; q < STEPS; q++) {
+                float v = 0.f;
+#pragma unroll
+                for (int ci = 0; ci < CIN; ci++) v = fmaf(xv[q][ci], wk[ci], v);
+                if (ok[q]) acc[dl[q] * COUT + co] += v;  // rows of one offset are distinct: plain read-modify-write
+            }
+        }
+        __syncthreads();  // offsets are phases: fixed per-row summation order
+    }
+    const int64_t row0 = (int64_t)tile * TR;
+    for (int idx = threadIdx.x; idx < TR * COUT; idx += 256) {
+        int r = idx / COUT;
+        if (row0 + r < n_dst) Y[(size_t)row0 * COUT + idx] = acc[idx];
+    }
+}
+
+// Any channel counts (odd test sizes): same tile / sub-chunk walk, scalar FMA.
 __global__ __launch_bounds__(256) void conv_tile_generic_kernel(
     const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ Y,
     const int32_t *__restrict__ tile_sub_start, const int32_t *__restrict__ tile_seg,
@@ -430,12 +495,34 @@ int conv_forward(const TiledRules &t, const float *X, const float *W, const floa
         FWD_BOTH_SLJ(7, 1, 1) FWD_BOTH_SLJ(8, 1, 1) FWD_BOTH_SLJ(9, 1, 1) FWD_BOTH_SLJ(10, 1, 1) FWD_BOTH_SLJ(11, 1, 1)
         FWD_BOTH_SLJ(12, 1, 1) FWD_BOTH_SLJ(13, 1, 1) FWD_BOTH_SLJ(14, 1, 1) FWD_BOTH_SLJ(15, 1, 1) FWD_BOTH_SLJ(16, 1, 1)
         // alternates reachable through SEI_FWD_PLAN (kernel experiments)
-        FWD_CASE(2, 1, 2, 4) FWD_CASE(4, 1, 2, 4) FWD_CASE(6, 1, 2, 4)
+        FWD_CASE(2, 1, 2, 4) FWD_CASE(4, 1, 2, 4) FWD_CASE(6, 1, 2, 4) FWD_CASE(2, 1, 1, 4) FWD_CASE(4, 1, 1, 4) FWD_CASE(6, 1, 1, 4)
         FWD_CASE(2, 1, 2, 1) FWD_CASE(4, 1, 2, 1) FWD_CASE(6, 1, 2, 1)
         FWD_CASE(4, 2, 2, 2) FWD_CASE(5, 2, 2, 2) FWD_CASE(6, 2, 2, 2) FWD_CASE(3, 2, 2, 2)
         FWD_CASE(4, 2, 2, 4) FWD_CASE(5, 2, 2, 4) FWD_CASE(6, 2, 2, 4) FWD_CASE(3, 2, 2, 4) FWD_CASE(2, 2, 2, 4) FWD_CASE(1, 2, 2, 4)
         FWD_CASE(8, 1, 2, 2) FWD_CASE(4, 2, 1, 2) FWD_CASE(5, 2, 1, 2) FWD_CASE(6, 2, 1, 2)
         SEI_FAIL("conv_forward: no MFMA instantiation for this plan");
+    }
+    if (nIn <= 4 && (nOut == 16 || nOut == 32 || nOut == 64)) {
+        size_t lds_small = ((size_t)t.tile_rows * nOut + (size_t)t.K * nIn * nOut) * sizeof(float);
+        if (lds_small <= 160 * 1024) {
+#define SMF(CIN_, COUT_)                                                                                           \
+    do {                                                                                                           \
+        static bool a_ = false;                                                                                    \
+        if (!a_) {                                                                                                 \
+            SEI_HIP(hipFuncSetAttribute((const void *)conv_tile_smallcin_kernel<CIN_, COUT_>,                      \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                 \
+            a_ = true;                                                                                             \
+        }                                                                                                          \
+        conv_tile_smallcin_kernel<CIN_, COUT_><<<t.n_tiles, 256, lds_small, st>>>(                                 \
+            X, W, bias, Y, t.tile_sub_start, t.tile_seg, t.sub_src, t.sub_dst, t.n_dst, t.K, t.tile_rows);         \
+    } while (0)
+#define SMFC(CIN_) do { if (nOut == 16) SMF(CIN_, 16); else if (nOut == 32) SMF(CIN_, 32); else SMF(CIN_, 64); } while (0)
+            if (nIn == 1) SMFC(1); else if (nIn == 2) SMFC(2); else if (nIn == 3) SMFC(3); else SMFC(4);
+#undef SMFC
+#undef SMF
+            SEI_LAUNCH_CHECK();
+            return 0;
+        }
     }
     if (p.lds_bytes > 160 * 1024) SEI_FAIL("conv: nOut too large for the generic kernel");
     static bool attr_set = false;
