@@ -133,6 +133,14 @@ int sei_sparse_to_dense_forward(sei_metadata_t *m, const int32_t spatial[3], con
 int sei_sparse_to_dense_backward(sei_metadata_t *m, const int32_t spatial[3], const float *ddense, int32_t C,
                                  float *dfeats, sei_stream_t stream);
 
+/* ---- fused sparse head (opt-in): AvgPool3d_full(tanh(SparseToDense(x))) without the dense
+ *      tensor (resnet.py:156-159 + classification_head.py:19-21): pooled[B,C] = sum_active tanh(x) / volume.
+ *      Uses float atomics: equal to the dense path within rounding, summation order not fixed. */
+int sei_pool_tanh_forward(sei_metadata_t *m, const int32_t spatial[3], const float *feats, int32_t C, float *pooled,
+                          sei_stream_t stream);
+int sei_pool_tanh_backward(sei_metadata_t *m, const int32_t spatial[3], const float *feats, const float *dpooled,
+                           int32_t C, float *dfeats, sei_stream_t stream);
+
 /* ---- measurement hooks (bench.py roofline leg): HIP events around each conv launch -------- */
 /* kinds: 0 conv_fwd, 1 conv_bwd_input, 2 conv_bwd_weight, 3 rulebook_build, 4 batchnorm, 5 other */
 int sei_prof_enable(int32_t on);

@@ -47,6 +47,8 @@ _SIGNATURES = {
     "sei_add_leaky_forward": (ctypes.c_int, [vp, vp, vp, ctypes.c_int64, ctypes.c_float, vp]),
     "sei_sparse_to_dense_forward": (ctypes.c_int, [vp, c_i32p, vp, ctypes.c_int32, vp, vp]),
     "sei_sparse_to_dense_backward": (ctypes.c_int, [vp, c_i32p, vp, ctypes.c_int32, vp, vp]),
+    "sei_pool_tanh_forward": (ctypes.c_int, [vp, c_i32p, vp, ctypes.c_int32, vp, vp]),
+    "sei_pool_tanh_backward": (ctypes.c_int, [vp, c_i32p, vp, vp, ctypes.c_int32, vp, vp]),
     "sei_prof_enable": (ctypes.c_int, [ctypes.c_int32]),
     "sei_prof_reset": (ctypes.c_int, []),
     "sei_prof_query": (ctypes.c_int, [ctypes.c_int32, ctypes.POINTER(ctypes.c_double)]),

@@ -411,6 +411,21 @@ int sei_sparse_to_dense_backward(sei_metadata_t *m, const int32_t spatial[3], co
     return sparse_to_dense(l, m->batch_size, dfeats, C, const_cast<float *>(ddense), true, (hipStream_t)stream);
 }
 
+int sei_pool_tanh_forward(sei_metadata_t *m, const int32_t spatial[3], const float *feats, int32_t C, float *pooled,
+                          sei_stream_t stream) {
+    std::lock_guard<std::mutex> lk(m->mu);
+    Level *l = find_level(m, spatial);
+    if (!l) SEI_FAIL("pool_tanh: no level with this spatial size in the metadata");
+    return pool_tanh(l, m->batch_size, feats, C, pooled, nullptr, nullptr, (hipStream_t)stream);
+}
+int sei_pool_tanh_backward(sei_metadata_t *m, const int32_t spatial[3], const float *feats, const float *dpooled,
+                           int32_t C, float *dfeats, sei_stream_t stream) {
+    std::lock_guard<std::mutex> lk(m->mu);
+    Level *l = find_level(m, spatial);
+    if (!l) SEI_FAIL("pool_tanh: no level with this spatial size in the metadata");
+    return pool_tanh(l, m->batch_size, feats, C, nullptr, dpooled, dfeats, (hipStream_t)stream);
+}
+
 int sei_prof_enable(int32_t on) {
     std::lock_guard<std::mutex> lk(g_prof.mu);
     g_prof.on = on != 0;

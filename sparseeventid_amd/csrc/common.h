@@ -180,6 +180,8 @@ int leaky_backward(const float *y, const float *dy, float *dx, int64_t count, fl
 int add_forward(const float *a, const float *b, float *out, int64_t count, float leak, bool act, hipStream_t st);
 int sparse_to_dense(const Level *lv, int batch, const float *feats, int C, float *dense, bool backward,
                     hipStream_t st);
+int pool_tanh(const Level *lv, int batch, const float *feats, int C, float *out, const float *dout, float *dfeats,
+              hipStream_t st);
 
 // ---- profiling (HIP events around launches) ----
 enum ProfKind { PROF_CONV_FWD = 0, PROF_CONV_BWD_IN = 1, PROF_CONV_BWD_W = 2, PROF_RULES = 3, PROF_BN = 4, PROF_OTHER = 5, PROF_NKIND = 6 };

@@ -406,6 +406,46 @@ __global__ void sparse_to_dense_kernel(const int32_t *__restrict__ coords, int64
         dense[off] = feats[t];
 }
 
+// ------------------------------------------------------------------ fused sparse head
+// AvgPool3d(tanh(SparseToDense(x))) over the full spatial extent == sum over ACTIVE rows of tanh(x) / V,
+// because tanh(0) = 0: the [B,C,D0,D1,D2] dense tensor never has to exist.  out[b][c] += tanh(f[row][c]) / V.
+__global__ void pool_tanh_fwd_kernel(const int32_t *__restrict__ coords, int64_t n, int C, float inv_vol,
+                                     const float *__restrict__ feats, float *__restrict__ out) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * C) return;
+    int64_t r = t / C;
+    int c = (int)(t - r * C);
+    int b = coords[4 * r + 3];
+    atomicAdd(&out[(size_t)b * C + c], tanhf(feats[t]) * inv_vol);
+}
+
+__global__ void pool_tanh_bwd_kernel(const int32_t *__restrict__ coords, int64_t n, int C, float inv_vol,
+                                     const float *__restrict__ feats, const float *__restrict__ dout,
+                                     float *__restrict__ dfeats) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * C) return;
+    int64_t r = t / C;
+    int c = (int)(t - r * C);
+    int b = coords[4 * r + 3];
+    float th = tanhf(feats[t]);
+    dfeats[t] = dout[(size_t)b * C + c] * inv_vol * (1.f - th * th);
+}
+
+int pool_tanh(const Level *lv, int batch, const float *feats, int C, float *out, const float *dout, float *dfeats,
+              hipStream_t st) {
+    const double vol = (double)lv->spatial[0] * lv->spatial[1] * lv->spatial[2];
+    if (!dout) SEI_HIP(hipMemsetAsync(out, 0, (size_t)batch * C * sizeof(float), st));
+    if (lv->n == 0) return 0;
+    int64_t tot = lv->n * C;
+    unsigned nb = (unsigned)((tot + 255) / 256);
+    if (!dout)
+        pool_tanh_fwd_kernel<<<nb, 256, 0, st>>>(lv->coords, lv->n, C, (float)(1.0 / vol), feats, out);
+    else
+        pool_tanh_bwd_kernel<<<nb, 256, 0, st>>>(lv->coords, lv->n, C, (float)(1.0 / vol), feats, dout, dfeats);
+    SEI_LAUNCH_CHECK();
+    return 0;
+}
+
 int sparse_to_dense(const Level *lv, int batch, const float *feats, int C, float *dense, bool backward,
                     hipStream_t st) {
     size_t vol = (size_t)lv->spatial[0] * lv->spatial[1] * lv->spatial[2];

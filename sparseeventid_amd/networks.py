@@ -167,6 +167,21 @@ class Encoder(nn.Module):
         x = self.pool(x)
         return torch.tanh(x)
 
+    def forward_pooled(self, x):
+        """Opt-in fused sparse head: returns AvgPool3d_full(forward(x)) as [B, C, 1, 1, 1] without materialising
+        the dense tensor (tanh(0) = 0, so only active rows contribute).  ``multi_head_output.forward_pooled``
+        consumes it.  The default ``forward`` keeps the reference's dense output."""
+        x = self.input_layer(x)
+        x = self.initial_convolution(x)
+        for l in self.network_layers:
+            x = l(x)
+        x = self.final_layer(x)
+        x = self.bottleneck(x)
+        if [int(v) for v in x.spatial_size] != [int(v) for v in self.output_shape[1:]]:
+            raise RuntimeError("fused head: final spatial size %r differs from output_shape %r"
+                               % (x.spatial_size, self.output_shape))
+        return scn.pool_tanh(x)[:, :, None, None, None]
+
     def increase_filters(self, current_filters, params):
         if _enum_name(params.growth_rate) == "multiplicative":
             return current_filters * 2
@@ -202,6 +217,11 @@ class multi_head_output(nn.Module):
             pooled = x.mean(dim=(2, 3, 4), keepdim=True)
             return {key: heads[key][1:](pooled) for key in heads.keys()}
         return {key: heads[key](x) for key in heads.keys()}
+
+
+    def forward_pooled(self, pooled):
+        heads = self.classification_head
+        return {key: heads[key][1:](pooled) for key in heads.keys()}
 
 
 def _full_window(pool, x):

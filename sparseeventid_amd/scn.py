@@ -350,6 +350,33 @@ def larcv_to_scn_device(larcv_batch):
     return coords[:n.value], feats[:n.value], B
 
 
+class _PoolTanh(torch.autograd.Function):
+    """pooled[B,C] = sum over active rows of tanh(x) / volume  ==  AvgPool3d_full(tanh(SparseToDense(x)))."""
+
+    @staticmethod
+    def forward(ctx, features, metadata, spatial):
+        B, C = metadata.batch_size(), features.shape[1]
+        ctx.md, ctx.spatial = metadata, spatial
+        ctx.save_for_backward(features)
+        out = torch.empty((B, C), dtype=torch.float32, device=features.device)
+        check(lib().sei_pool_tanh_forward(metadata.handle, i32x3(spatial), _ptr(features), C, _ptr(out), _stream()))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (features,) = ctx.saved_tensors
+        dout = _f32c(dout)
+        dfeat = torch.empty_like(features)
+        check(lib().sei_pool_tanh_backward(ctx.md.handle, i32x3(ctx.spatial), _ptr(features), _ptr(dout),
+                                           features.shape[1], _ptr(dfeat), _stream()))
+        return dfeat, None, None
+
+
+def pool_tanh(input):
+    """Fused sparse head input (opt-in): global average of tanh over the full spatial extent, [B, C]."""
+    return _PoolTanh.apply(_f32c(input.features), input.metadata, _triple(input.spatial_size))
+
+
 # ============================================================================= functional helpers
 def batchnorm_act(x, bn, leak=1.0, residual=None):
     """Fused BatchNormalization (+AddTable residual) + LeakyReLU on a features tensor."""

@@ -43,9 +43,10 @@ class Trainer:
     """Owns encoder + heads (reference topology), the flat parameter/gradient arenas and Adam."""
 
     def __init__(self, cfg=None, image_size=None, output_shape=None, weight_decay=1e-6, lr_schedule=None,
-                 device="cuda", seed=0, model="resnet", sbnd_cfg=None):
+                 device="cuda", seed=0, model="resnet", sbnd_cfg=None, fused_head=False):
         self.cfg = cfg or Config()
         self.model = model
+        self.fused_head = fused_head and model != "sbnd"   # opt-in: skips the dense tensor (SURVEY 8f.3)
         torch.manual_seed(seed)
         if model == "sbnd":
             # legacy multiplane network (src/networks/torch/sparseresnet.py): logits come straight out of it
@@ -86,6 +87,8 @@ class Trainer:
         return (c, f, bs), lab
 
     def forward(self, image):
+        if self.fused_head:
+            return self.head.forward_pooled(self.encoder.forward_pooled(image))
         return self.head(self.encoder(image))
 
     def train_step(self, image, labels):

@@ -80,3 +80,24 @@ def test_encoder_head_loss_parity(dimension, image_size, kw):
     # running statistics (BN buffers) agree too
     for k, b in enc.named_buffers():
         assert rel_err(b, osd[k]) < 1e-4, k
+
+
+def test_fused_sparse_head_equals_dense_path():
+    """Opt-in fused head: sum_active tanh(x)/V == AvgPool3d(tanh(SparseToDense(x)))."""
+    torch.manual_seed(1)
+    kw = dict(depth=2, n_initial_filters=16, n_output_filters=16, blocks_per_layer=1)
+    enc, head = _build(kw, [1, 32, 32, 32])
+    enc.train(); head.eval()
+    coords, feats = blob_cloud(9, 3, [32, 32, 32], 300, 1)
+    x = (torch.from_numpy(coords), torch.from_numpy(feats), 3)
+    dense_logits = head(enc(x))
+    loss_d = sum(v.square().sum() for v in dense_logits.values())
+    loss_d.backward()
+    g_dense = enc.bottleneck.weight.grad.clone()
+    enc.zero_grad(); head.zero_grad()
+    fused_logits = head.forward_pooled(enc.forward_pooled(x))
+    loss_f = sum(v.square().sum() for v in fused_logits.values())
+    loss_f.backward()
+    for k in HEADS:
+        assert rel_err(fused_logits[k], dense_logits[k]) < 1e-5
+    assert rel_err(enc.bottleneck.weight.grad, g_dense) < 1e-4
