@@ -15,6 +15,8 @@
 //   (rules are the contraction dimension); partial slabs are summed in a fixed order.
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace sei {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -380,19 +382,22 @@ int conv_backward_weight(const TiledRules &t, const float *X, const float *dY, f
     int mt = 0;
     if (mfma_ok) {
         int ct = nIn / 16;
-        // widest ci block whose accumulators fit (<= 64 16x16 tiles = 256 registers)
-        const int cands[] = {8, 6, 5, 4, 3, 2, 1};
+        // ci block height: <= 24 accumulator tiles (96 registers) keeps 3 waves per SIMD resident, which measured
+        // faster than wider register tiles at 2 waves (C=96: 6x6 tiles 1.38 ms -> 3x6 tiles 1.17 ms)
+        const int cands[] = {4, 3, 2, 1};
         for (int cand : cands) {
-            bool inst = cand <= 4 ? (cand * nt <= 48 && (nt <= 6 || nt == 8 || nt == 10 || nt == 12 || cand == 1 ||
-                                                          (cand == 2 && (nt == 7 || nt == 14 || nt == 16)))) :
-                        ((cand == 6 && (nt == 6 || nt == 8)) || (cand == 5 && (nt == 10 || nt == 12)) ||
-                         (cand == 8 && nt == 8));
+            bool inst = (cand == 1) || (cand * nt <= 24 && (nt <= 6 || nt == 8 || nt == 10 || nt == 12)) ||
+                        (cand == 2 && (nt == 7 || nt == 14 || nt == 16));
             if (ct % cand == 0 && inst) {
                 mt = cand;
                 break;
             }
         }
         if (!mt) mfma_ok = false;
+        if (const char *e = getenv("SEI_DW_MT")) {  // kernel experiments
+            int em = atoi(e);
+            if (em >= 1 && em <= 4 && ct % em == 0 && em * nt <= 48) mt = em;
+        }
     }
     bool small = !mfma_ok && nIn <= 4 && (nOut == 16 || nOut == 32 || nOut == 64);
     // splits: a split's dY / X rows (re-read by the K workgroups of that split, which share an XCD) should fit
