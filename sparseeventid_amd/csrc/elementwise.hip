@@ -172,10 +172,19 @@ __global__ void bn_apply_kernel(const float *__restrict__ x, const float *__rest
                                 int64_t total_vec, int C, const float *__restrict__ mean,
                                 const float *__restrict__ invstd, const float *__restrict__ gamma,
                                 const float *__restrict__ beta, float leak) {
+    // the host picks the grid so that stride*VEC is a multiple of C: every thread keeps ONE channel group and
+    // its parameters live in registers (no per-element modulo / parameter loads)
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int c = (int)((t * VEC) % C);
+    float sc[VEC], sh[VEC], mu[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; v++) {
+        sc[v] = invstd[c + v] * (gamma ? gamma[c + v] : 1.f);
+        sh[v] = beta ? beta[c + v] : 0.f;
+        mu[v] = mean[c + v];
+    }
     for (; t < total_vec; t += stride) {
-        int c = (int)((t * VEC) % C);
         float xv[VEC], rv[VEC], o[VEC];
         if (VEC == 4) {
             float4 a = reinterpret_cast<const float4 *>(x)[t];
@@ -190,8 +199,7 @@ __global__ void bn_apply_kernel(const float *__restrict__ x, const float *__rest
         }
 #pragma unroll
         for (int v = 0; v < VEC; v++) {
-            float g = gamma ? gamma[c + v] : 1.f, b = beta ? beta[c + v] : 0.f;
-            float z = (xv[v] - mean[c + v]) * (invstd[c + v] * g) + b;
+            float z = (xv[v] - mu[v]) * sc[v] + sh[v];
             if (res) z += rv[v];
             o[v] = z > 0.f ? z : z * leak;
         }
@@ -210,8 +218,17 @@ __global__ void bn_bwd_apply_kernel(const float *__restrict__ x, const float *__
                                     const float *__restrict__ coef /*[2][C] or null (eval)*/, float leak) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int c = (int)((t * VEC) % C);  // constant per thread: the grid is sized so that stride*VEC % C == 0
+    float gs[VEC], is_[VEC], mu[VEC], c0[VEC], c1[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; v++) {
+        is_[v] = invstd[c + v];
+        gs[v] = (gamma ? gamma[c + v] : 1.f) * is_[v];
+        mu[v] = mean[c + v];
+        c0[v] = coef ? coef[c + v] : 0.f;
+        c1[v] = coef ? coef[C + c + v] : 0.f;
+    }
     for (; t < total_vec; t += stride) {
-        int c = (int)((t * VEC) % C);
         float xv[VEC], yv[VEC], dv[VEC], o[VEC], dz[VEC];
         if (VEC == 4) {
             float4 a = reinterpret_cast<const float4 *>(x)[t];
@@ -226,13 +243,11 @@ __global__ void bn_bwd_apply_kernel(const float *__restrict__ x, const float *__
 #pragma unroll
         for (int v = 0; v < VEC; v++) {
             dz[v] = yv[v] > 0.f ? dv[v] : dv[v] * leak;
-            float g = gamma ? gamma[c + v] : 1.f;
-            float is = invstd[c + v];
             if (coef) {
-                float xh = (xv[v] - mean[c + v]) * is;
-                o[v] = g * is * (dz[v] - coef[c + v] - xh * coef[C + c + v]);
+                float xh = (xv[v] - mu[v]) * is_[v];
+                o[v] = gs[v] * (dz[v] - c0[v] - xh * c1[v]);
             } else {
-                o[v] = g * is * dz[v];
+                o[v] = gs[v] * dz[v];
             }
         }
         if (VEC == 4) {
@@ -258,6 +273,17 @@ static inline unsigned ew_blocks(int64_t total_vec) {
     return (unsigned)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
 }
 
+// grid for the per-channel kernels: a multiple of m = C / gcd(C, 256*vec) blocks, so that the grid stride (in
+// floats) is a multiple of C and every thread keeps its channel group
+static inline unsigned bn_blocks(int64_t total_vec, int C, int vec) {
+    int a = C, b = 256 * vec;
+    while (b) { int r = a % b; a = b; b = r; }
+    const unsigned m = (unsigned)(C / a);
+    unsigned blocks = ew_blocks(total_vec);
+    blocks = blocks / m * m;
+    return blocks < m ? m : blocks;
+}
+
 int bn_forward(const float *x, int64_t n, int C, const float *gamma, const float *beta, float *rmean, float *rvar,
                float eps, float momentum, int training, float leak, const float *residual, float *y, float *save_mean,
                float *save_invstd, hipStream_t st) {
@@ -279,10 +305,10 @@ int bn_forward(const float *x, int64_t n, int C, const float *gamma, const float
     }
     if (C % 4 == 0) {
         int64_t tv = n * C / 4;
-        bn_apply_kernel<4><<<ew_blocks(tv), 256, 0, st>>>(x, residual, y, tv, C, save_mean, save_invstd, gamma, beta, leak);
+        bn_apply_kernel<4><<<bn_blocks(tv, C, 4), 256, 0, st>>>(x, residual, y, tv, C, save_mean, save_invstd, gamma, beta, leak);
     } else {
         int64_t tv = n * C;
-        bn_apply_kernel<1><<<ew_blocks(tv), 256, 0, st>>>(x, residual, y, tv, C, save_mean, save_invstd, gamma, beta, leak);
+        bn_apply_kernel<1><<<bn_blocks(tv, C, 1), 256, 0, st>>>(x, residual, y, tv, C, save_mean, save_invstd, gamma, beta, leak);
     }
     SEI_LAUNCH_CHECK();
     return 0;
@@ -308,10 +334,10 @@ int bn_backward(const float *x, const float *y, const float *dy, int64_t n, int 
     const float *cf = training ? coef : nullptr;
     if (C % 4 == 0) {
         int64_t tv = n * C / 4;
-        bn_bwd_apply_kernel<4><<<ew_blocks(tv), 256, 0, st>>>(x, y, dy, dx, dres, tv, C, save_mean, save_invstd, gamma, cf, leak);
+        bn_bwd_apply_kernel<4><<<bn_blocks(tv, C, 4), 256, 0, st>>>(x, y, dy, dx, dres, tv, C, save_mean, save_invstd, gamma, cf, leak);
     } else {
         int64_t tv = n * C;
-        bn_bwd_apply_kernel<1><<<ew_blocks(tv), 256, 0, st>>>(x, y, dy, dx, dres, tv, C, save_mean, save_invstd, gamma, cf, leak);
+        bn_bwd_apply_kernel<1><<<bn_blocks(tv, C, 1), 256, 0, st>>>(x, y, dy, dx, dres, tv, C, save_mean, save_invstd, gamma, cf, leak);
     }
     SEI_LAUNCH_CHECK();
     pool_free(coef);

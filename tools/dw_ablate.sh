@@ -1,0 +1,14 @@
+#!/bin/bash
+for spec in "1 64" "2 96" "3 128"; do set -- $spec
+ for ab in 0; do
+  export SEI_ABLATE=$ab
+  rm -rf gpurun_out/dwp; rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/dwp -- python3 tools/conv_micro.py --level $1 --cin $2 --cout $2 --events 16 --iters 3 --bwd > /dev/null 2>&1
+  python3 - <<PY
+import csv,glob
+f=glob.glob('gpurun_out/dwp/*/*_kernel_stats.csv')[0]
+for r in csv.DictReader(open(f)):
+    if 'conv_dw_mfma' in r['Name']:
+        print("L$1 C=$2 ablate=$ab", r['Name'].split('(')[0][-28:], "avg us", float(r['AverageNs'])/1e3)
+PY
+ done
+done
