@@ -66,6 +66,15 @@ __host__ __device__ inline uint64_t mix64(uint64_t k) {
     return k;
 }
 
+// Locality-preserving slot choice: the 8 keys that differ only in the low 3 bits of x2 (the fastest coordinate)
+// share one 8-slot block = one 64-byte line of `keys`; the block is placed by the hash of the other bits.
+// Collisions step by 8 slots, i.e. to the same position of the next block.  Probes of neighbouring sites along
+// x2 -- what consecutive lanes of the rulebook probe kernel issue -- then hit the same cache line.
+__host__ __device__ inline uint64_t hash_slot0(uint64_t key, uint64_t mask) {
+    return ((mix64(key >> 3) << 3) | (key & 7ull)) & mask;
+}
+__host__ __device__ inline uint64_t hash_next(uint64_t s, uint64_t mask) { return (s + 8) & mask; }
+
 struct HashTable {
     uint64_t *keys = nullptr;
     uint32_t *vals = nullptr;

@@ -98,7 +98,7 @@ int exclusive_scan_i32(const int32_t *in, int32_t *out, int64_t n, int32_t *tota
 // Insert key; the slot's value becomes the MIN candidate id that hit it (deterministic
 // representative = first appearance).  Returns the slot.
 __device__ inline uint32_t hash_insert_min(uint64_t *keys, uint32_t *vals, uint64_t mask, uint64_t key, uint32_t cand) {
-    uint64_t s = mix64(key) & mask;
+    uint64_t s = hash_slot0(key, mask);
     for (;;) {
         unsigned long long prev = atomicCAS((unsigned long long *)&keys[s], (unsigned long long)EMPTY_KEY,
                                             (unsigned long long)key);
@@ -106,7 +106,7 @@ __device__ inline uint32_t hash_insert_min(uint64_t *keys, uint32_t *vals, uint6
             atomicMin(&vals[s], cand);
             return (uint32_t)s;
         }
-        s = (s + 1) & mask;
+        s = hash_next(s, mask);
     }
 }
 

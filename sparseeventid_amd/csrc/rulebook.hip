@@ -8,12 +8,12 @@ namespace sei {
 
 __device__ inline int hash_find(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, uint64_t mask,
                                 uint64_t key) {
-    uint64_t s = mix64(key) & mask;
+    uint64_t s = hash_slot0(key, mask);
     for (;;) {
         uint64_t k = keys[s];
         if (k == key) return (int)vals[s];
         if (k == EMPTY_KEY) return -1;
-        s = (s + 1) & mask;
+        s = hash_next(s, mask);
     }
 }
 
@@ -217,7 +217,7 @@ __device__ inline bool candidate(int4 p, int j, const ProbeGeom &g, int o0, int 
 }
 
 __device__ inline uint32_t hash_insert_min_dev(uint64_t *keys, uint32_t *vals, uint64_t mask, uint64_t key, uint32_t cand) {
-    uint64_t s = mix64(key) & mask;
+    uint64_t s = hash_slot0(key, mask);
     for (;;) {
         unsigned long long prev = atomicCAS((unsigned long long *)&keys[s], (unsigned long long)EMPTY_KEY,
                                             (unsigned long long)key);
@@ -225,7 +225,7 @@ __device__ inline uint32_t hash_insert_min_dev(uint64_t *keys, uint32_t *vals, u
             atomicMin(&vals[s], cand);
             return (uint32_t)s;
         }
-        s = (s + 1) & mask;
+        s = hash_next(s, mask);
     }
 }
 
