@@ -120,7 +120,7 @@ struct ProbeGeom {
 
 }  // namespace sei
 
-constexpr int SEI_NVARIANT = 3;  // tile_rows 256 / 128 / 64
+constexpr int SEI_NVARIANT = 4;  // tile_rows 64 / 128 / 192 / 256
 struct sei_rulebook {
     sei::TiledRules fwd[SEI_NVARIANT];  // dst = output rows, src = input rows
     sei::TiledRules bwd[SEI_NVARIANT];  // dst = input rows,  src = output rows (strided conv only)
@@ -157,7 +157,7 @@ int exclusive_scan_i32(const int32_t *in, int32_t *out, int64_t n, int32_t *tota
 int larcv_compact(const float *in, int B, int P, int M, int D, int32_t *coords, float *feats, int64_t *n_out,
                   hipStream_t st);
 // rulebook.hip
-inline int variant_of(int tile_rows) { return tile_rows == 256 ? 0 : (tile_rows == 128 ? 1 : 2); }
+inline int variant_of(int tile_rows) { return tile_rows / 64 - 1; }
 // returns the (lazily built) tiled rules of the rulebook: transposed=false -> fwd, true -> bwd
 int get_tiled(sei_rulebook *rb, bool transposed, int tile_rows, const TiledRules **out, hipStream_t st);
 // any already-built variant (prefers 256 rows), building the 256 one if none exists

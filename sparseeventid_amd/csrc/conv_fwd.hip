@@ -432,7 +432,7 @@ static FwdPlan plan_forward(int nIn, int nOut, int K) {
         int em, ec, es;
         const bool forced = env_plan(nOut, &em, &ec, &es);
         if (forced) {
-            if ((nOut / 16) % ec == 0 && (em == 1 || em == 2 || em == 4) && (ec == 1 || ec == 2)) {
+            if ((nOut / 16) % ec == 0 && em >= 1 && em <= 4 && (ec == 1 || ec == 2)) {
                 p.maxs = em; p.cs = ec;
                 if (es == 1 || (es == 2 && nIn % 32 == 0)) p.slj = es;
             }
@@ -496,7 +496,7 @@ int conv_forward(const TiledRules &t, const float *X, const float *W, const floa
         FWD_BOTH_SLJ(12, 1, 1) FWD_BOTH_SLJ(13, 1, 1) FWD_BOTH_SLJ(14, 1, 1) FWD_BOTH_SLJ(15, 1, 1) FWD_BOTH_SLJ(16, 1, 1)
         // alternates reachable through SEI_FWD_PLAN (kernel experiments)
         FWD_CASE(2, 1, 2, 4) FWD_CASE(4, 1, 2, 4) FWD_CASE(6, 1, 2, 4) FWD_CASE(2, 1, 1, 4) FWD_CASE(4, 1, 1, 4) FWD_CASE(6, 1, 1, 4)
-        FWD_CASE(2, 1, 2, 1) FWD_CASE(4, 1, 2, 1) FWD_CASE(6, 1, 2, 1)
+        FWD_CASE(2, 1, 2, 1) FWD_CASE(4, 1, 2, 1) FWD_CASE(6, 1, 2, 1) FWD_CASE(2, 1, 2, 3) FWD_CASE(4, 1, 2, 3)
         FWD_CASE(4, 2, 2, 2) FWD_CASE(5, 2, 2, 2) FWD_CASE(6, 2, 2, 2) FWD_CASE(3, 2, 2, 2)
         FWD_CASE(4, 2, 2, 4) FWD_CASE(5, 2, 2, 4) FWD_CASE(6, 2, 2, 4) FWD_CASE(3, 2, 2, 4) FWD_CASE(2, 2, 2, 4) FWD_CASE(1, 2, 2, 4)
         FWD_CASE(8, 1, 2, 2) FWD_CASE(4, 2, 1, 2) FWD_CASE(5, 2, 1, 2) FWD_CASE(6, 2, 1, 2)

@@ -166,7 +166,7 @@ static int build_tiled(const int32_t *dst_coords, int64_t n_dst, int64_t n_src, 
 }
 
 int get_tiled(sei_rulebook *rb, bool transposed, int tile_rows, const TiledRules **out, hipStream_t st) {
-    if (tile_rows != 256 && tile_rows != 128 && tile_rows != 64) SEI_FAIL("rulebook: tile_rows must be 256, 128 or 64");
+    if (tile_rows < 64 || tile_rows > 256 || tile_rows % 64) SEI_FAIL("rulebook: tile_rows must be 64, 128, 192 or 256");
     std::lock_guard<std::mutex> lk(rb->mu);
     if (rb->submanifold) transposed = false;
     TiledRules &t = (transposed ? rb->bwd : rb->fwd)[variant_of(tile_rows)];
