@@ -97,6 +97,10 @@ int sei_conv_forward(sei_rulebook_t *rb, const float *X, const float *W, const f
 /* dX[n_src,nIn] = sum_k dY[rule.out] * W[k]^T */
 int sei_conv_backward_input(sei_rulebook_t *rb, const float *dY, const float *W, float *dX,
                             int32_t nIn, int32_t nOut, sei_stream_t stream);
+/* dX = dX_init + sum_k dY[rule.out] * W[k]^T : the residual branch's gradient is folded into the convolution's
+ * accumulator initialisation instead of a separate [n,nIn] add pass (plane counts of the MFMA kernel only). */
+int sei_conv_backward_input_accumulate(sei_rulebook_t *rb, const float *dY, const float *W, const float *dX_init,
+                                       float *dX, int32_t nIn, int32_t nOut, sei_stream_t stream);
 /* dW[K,nIn,nOut] = sum_rules X[rule.in]^T dY[rule.out]; dbias[nOut] = colsum(dY) if non-NULL */
 int sei_conv_backward_weight(sei_rulebook_t *rb, const float *X, const float *dY, float *dW, float *dbias,
                              int32_t nIn, int32_t nOut, sei_stream_t stream);

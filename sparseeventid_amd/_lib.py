@@ -36,6 +36,7 @@ _SIGNATURES = {
     "sei_rulebook_export": (ctypes.c_int, [vp, c_i64p, vp, vp, vp]),
     "sei_conv_forward": (ctypes.c_int, [vp, vp, vp, vp, vp, ctypes.c_int32, ctypes.c_int32, vp]),
     "sei_conv_backward_input": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int32, ctypes.c_int32, vp]),
+    "sei_conv_backward_input_accumulate": (ctypes.c_int, [vp, vp, vp, vp, vp, ctypes.c_int32, ctypes.c_int32, vp]),
     "sei_conv_backward_weight": (ctypes.c_int, [vp, vp, vp, vp, vp, ctypes.c_int32, ctypes.c_int32, vp]),
     "sei_bn_forward": (ctypes.c_int, [vp, ctypes.c_int64, ctypes.c_int32, vp, vp, vp, vp, ctypes.c_float, ctypes.c_float,
                                       ctypes.c_int32, ctypes.c_float, vp, vp, vp, vp, vp]),

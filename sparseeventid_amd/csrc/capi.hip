@@ -335,23 +335,36 @@ int sei_conv_forward(sei_rulebook_t *rb, const float *X, const float *W, const f
     return rc;
 }
 
-int sei_conv_backward_input(sei_rulebook_t *rb, const float *dY, const float *W, float *dX, int32_t nIn, int32_t nOut,
-                            sei_stream_t stream) {
+static int conv_backward_input_impl(sei_rulebook_t *rb, const float *dY, const float *W, const float *dX_init, float *dX,
+                                    int32_t nIn, int32_t nOut, sei_stream_t stream) {
     if (!rb) SEI_FAIL("null rulebook");
     hipStream_t st = (hipStream_t)stream;
     const TiledRules *t;
     // roles swap: contraction over nOut, result has nIn columns
     SEI_TRY(get_tiled(rb, true, conv_tile_rows(nOut, nIn), &t, st));
+    if (dX_init && (!conv_supports_init(nOut, nIn) || t->n_sub == 0))
+        SEI_FAIL("conv_backward_input_accumulate: not supported for these plane counts");
     float *Wt;
     SEI_TRY(pool_alloc_t(&Wt, (size_t)t->K * nIn * nOut));
     // Wt[k'][co][ci] = W[K-1-k' (submanifold mirror) or k'][ci][co], columns (ci) permuted for the kernel
     int rc = conv_transform_weights(W, Wt, t->K, nIn, nOut, true, rb->submanifold, conv_col_group(nOut, nIn), st);
     if (!rc) {
         ProfScope ps(PROF_CONV_BWD_IN, st, 2.0 * t->n_rules * nIn * nOut, conv_bytes(*t, nOut, nIn));
-        rc = conv_forward(*t, dY, Wt, nullptr, dX, nOut, nIn, st);
+        rc = conv_forward(*t, dY, Wt, nullptr, dX, nOut, nIn, st, dX_init);
     }
     pool_free(Wt);
     return rc;
+}
+
+int sei_conv_backward_input(sei_rulebook_t *rb, const float *dY, const float *W, float *dX, int32_t nIn, int32_t nOut,
+                            sei_stream_t stream) {
+    return conv_backward_input_impl(rb, dY, W, nullptr, dX, nIn, nOut, stream);
+}
+
+int sei_conv_backward_input_accumulate(sei_rulebook_t *rb, const float *dY, const float *W, const float *dX_init,
+                                       float *dX, int32_t nIn, int32_t nOut, sei_stream_t stream) {
+    if (!dX_init) SEI_FAIL("sei_conv_backward_input_accumulate: null dX_init");
+    return conv_backward_input_impl(rb, dY, W, dX_init, dX, nIn, nOut, stream);
 }
 
 int sei_conv_backward_weight(sei_rulebook_t *rb, const float *X, const float *dY, float *dW, float *dbias, int32_t nIn,

@@ -168,7 +168,8 @@ int export_rules(const TiledRules &t, int64_t *start_host, int32_t *rin, int32_t
 // conv.hip
 int conv_tile_rows(int nIn, int nOut);  // tile size the forward kernel wants for these plane counts
 int conv_forward(const TiledRules &t, const float *X, const float *W, const float *bias, float *Y, int nIn, int nOut,
-                 hipStream_t st);
+                 hipStream_t st, const float *init = nullptr);
+bool conv_supports_init(int nIn, int nOut);
 int conv_col_group(int nIn, int nOut);
 // Wout[k][r][perm(c)]: transpose=false: rows=nIn, cols=nOut (forward); transpose=true: Wout[k][co][perm(ci)] = W[ks][ci][co]
 // with ks = flip ? K-1-k : k (dX).  perm = column permutation inside groups of `col_group` columns (0 = identity).

@@ -123,7 +123,8 @@ template <int NT, int CS, int SLJ, int MAXS>
 __global__ __launch_bounds__(256, occ_for(MAXS, NT, SLJ)) void conv_tile_mfma_kernel(
     const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ Y,
     const int32_t *__restrict__ tile_sub_start, const int32_t *__restrict__ tile_seg,
-    const int32_t *__restrict__ sub_src, const uint8_t *__restrict__ sub_dst, int64_t n_dst, int K, int CIN, int n_tiles) {
+    const int32_t *__restrict__ sub_src, const uint8_t *__restrict__ sub_dst, int64_t n_dst, int K, int CIN, int n_tiles,
+    const float *__restrict__ init) {
     extern __shared__ float lds[];
     constexpr int U = 4 / CS;  // units (groups of CS waves) dealing sub-chunks
     constexpr int TR = 16 * MAXS * U;
@@ -147,10 +148,13 @@ __global__ __launch_bounds__(256, occ_for(MAXS, NT, SLJ)) void conv_tile_mfma_ke
 
     for (int i = threadIdx.x; i <= K; i += 256) seg[i] = tile_seg[(size_t)tile * (K + 1) + i];
     {
+        // accumulators start from the bias, or from the rows of `init` (Y = init + conv: gradient accumulation)
         constexpr int V = COUT >> 2;
+        const int64_t row0i = (int64_t)tile * TR;
         for (int idx = threadIdx.x; idx < TR * V; idx += 256) {
             int r = idx / V, v = idx - r * V;
             float4 b = bias ? *reinterpret_cast<const float4 *>(bias + 4 * v) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (init && row0i + r < n_dst) b = *reinterpret_cast<const float4 *>(init + (size_t)(row0i + r) * COUT + 4 * v);
             *reinterpret_cast<float4 *>(acc_tile + (size_t)r * ASTRIDE + 4 * v) = b;
         }
     }
@@ -452,6 +456,8 @@ static FwdPlan plan_forward(int nIn, int nOut, int K) {
 int conv_tile_rows(int nIn, int nOut) { return plan_forward(nIn, nOut, 27).tile_rows; }
 
 // column-group width (floats) whose columns the forward kernel expects permuted; 0 = generic kernel, no permutation
+bool conv_supports_init(int nIn, int nOut) { return plan_forward(nIn, nOut, 27).mfma; }
+
 int conv_col_group(int nIn, int nOut) {
     FwdPlan p = plan_forward(nIn, nOut, 27);
     return p.mfma ? p.nt * 16 : 0;
@@ -459,7 +465,7 @@ int conv_col_group(int nIn, int nOut) {
 
 template <int NT, int CS, int SLJ, int MAXS>
 static int launch_mfma(const TiledRules &t, const FwdPlan &p, const float *X, const float *W, const float *bias,
-                       float *Y, int nIn, hipStream_t st) {
+                       float *Y, int nIn, const float *init, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
         SEI_HIP(hipFuncSetAttribute((const void *)conv_tile_mfma_kernel<NT, CS, SLJ, MAXS>,
@@ -467,26 +473,28 @@ static int launch_mfma(const TiledRules &t, const FwdPlan &p, const float *X, co
         attr_set = true;
     }
     conv_tile_mfma_kernel<NT, CS, SLJ, MAXS><<<((t.n_tiles + 7) / 8) * 8, 256, p.lds_bytes, st>>>(
-        X, W, bias, Y, t.tile_sub_start, t.tile_seg, t.sub_src, t.sub_dst, t.n_dst, t.K, nIn, t.n_tiles);
+        X, W, bias, Y, t.tile_sub_start, t.tile_seg, t.sub_src, t.sub_dst, t.n_dst, t.K, nIn, t.n_tiles, init);
     SEI_LAUNCH_CHECK();
     return 0;
 }
 
 #define FWD_CASE(NT_, CS_, SLJ_, MAXS_)                                            \
     if (p.nt == NT_ && p.cs == CS_ && p.slj == SLJ_ && p.maxs == MAXS_)            \
-        return launch_mfma<NT_, CS_, SLJ_, MAXS_>(t, p, X, W, bias, Y, nIn, st);
+        return launch_mfma<NT_, CS_, SLJ_, MAXS_>(t, p, X, W, bias, Y, nIn, init, st);
 #define FWD_BOTH_SLJ(NT_, CS_, MAXS_) FWD_CASE(NT_, CS_, 1, MAXS_) FWD_CASE(NT_, CS_, 2, MAXS_)
 
 int conv_forward(const TiledRules &t, const float *X, const float *W, const float *bias, float *Y, int nIn, int nOut,
-                 hipStream_t st) {
+                 hipStream_t st, const float *init) {
     if (t.n_dst == 0) return 0;
-    if (t.n_sub == 0) {
+    if (init && bias) SEI_FAIL("conv_forward: bias and init are mutually exclusive");
+    if (t.n_sub == 0 && !init) {
         int64_t tot = t.n_dst * nOut;
         fill_bias_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, st>>>(Y, t.n_dst, nOut, bias);
         SEI_LAUNCH_CHECK();
         return 0;
     }
     FwdPlan p = plan_forward(nIn, nOut, t.K);
+    if (init && (!p.mfma || t.n_sub == 0)) SEI_FAIL("conv_forward: init is only supported by the MFMA kernel");
     if (p.tile_rows != t.tile_rows) SEI_FAIL("conv_forward: rulebook tile size does not match the kernel plan");
     if (p.mfma) {
         // default plans

@@ -64,9 +64,15 @@ class ResidualBlock(nn.Module):
         self.add = scn.AddTable()
 
     def forward(self, x):
+        c1, c2 = self.convolution_1, self.convolution_2
+        if (c1._do_normalization and c2._do_normalization and isinstance(c1.activation, scn.LeakyReLU)
+                and c1.norm.affine and c2.norm.affine and c1.conv1.nIn == c1.conv1.nOut == c2.conv1.nOut
+                and c1.conv1.filter_size == c2.conv1.filter_size and scn.residual_block_supported(c1.conv1.nOut)
+                and x.features.shape[0] > 0 and x.features.is_cuda):
+            # whole block as one autograd node (skip gradient folded into conv1's dX kernel)
+            return scn.residual_block(x, c1.conv1, c1.norm, c2.conv1, c2.norm, c1.activation.leak, self.relu.leak)
         residual = self.residual(x)
         out = self.convolution_1(x)
-        c2 = self.convolution_2
         if c2._do_normalization:
             # conv -> [BN + residual add + LeakyReLU] fused: one read of each operand, one write
             y = c2.conv1(out)

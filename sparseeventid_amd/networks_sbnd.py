@@ -68,6 +68,9 @@ class SparseResidualBlock(nn.Module):
         self.add = scn.AddTable()
 
     def forward(self, x):
+        if (self.batch_norm and self.conv1.nIn == self.conv1.nOut and scn.residual_block_supported(self.conv1.nOut)
+                and x.features.shape[0] > 0 and x.features.is_cuda):
+            return scn.residual_block(x, self.conv1, self.bn1, self.conv2, self.bn2, self.bn1.leakiness, self.relu.leak)
         residual = self.residual(x)
         out = self.conv1(x)
         out = self.bn1(out) if self.batch_norm else self.relu(out)

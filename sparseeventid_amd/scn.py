@@ -262,6 +262,91 @@ class _BatchNorm(torch.autograd.Function):
         return dx, dgamma, dbeta, None, None, None, None, None, None, dres
 
 
+class _ResidualBlock(torch.autograd.Function):
+    """conv1 -> BN -> act -> conv2 -> BN -> (+x) -> act as ONE autograd node
+    (ResidualBlock, sparse_building_blocks.py:61-100; SparseResidualBlock, torch/sparseresnet.py:47-103).
+
+    Same kernels as the separate modules; the point of the node is the backward: the gradient of the skip
+    connection initialises the accumulators of conv1's dX kernel (dX = dres + conv^T(dY)) instead of a separate
+    [N,C] add, and five autograd nodes become one."""
+
+    @staticmethod
+    def forward(ctx, x, rb, w1, b1, g1, be1, rm1, rv1, w2, b2, g2, be2, rm2, rv2, eps, momentum, training, leak1, leak2):
+        n, C = x.shape
+        dev = x.device
+        L = lib()
+        st = _stream()
+        y1 = torch.empty_like(x)
+        check(L.sei_conv_forward(rb.h, _ptr(x), _ptr(w1), _ptr(b1), _ptr(y1), C, C, st))
+        a1 = torch.empty_like(x)
+        m1, s1 = torch.empty(C, device=dev), torch.empty(C, device=dev)
+        check(L.sei_bn_forward(_ptr(y1), n, C, _ptr(g1), _ptr(be1), _ptr(rm1), _ptr(rv1), eps, momentum,
+                               1 if training else 0, leak1, None, _ptr(a1), _ptr(m1), _ptr(s1), st))
+        y2 = torch.empty_like(x)
+        check(L.sei_conv_forward(rb.h, _ptr(a1), _ptr(w2), _ptr(b2), _ptr(y2), C, C, st))
+        out = torch.empty_like(x)
+        m2, s2 = torch.empty(C, device=dev), torch.empty(C, device=dev)
+        check(L.sei_bn_forward(_ptr(y2), n, C, _ptr(g2), _ptr(be2), _ptr(rm2), _ptr(rv2), eps, momentum,
+                               1 if training else 0, leak2, _ptr(x), _ptr(out), _ptr(m2), _ptr(s2), st))
+        ctx.rb, ctx.training, ctx.leak1, ctx.leak2 = rb, training, leak1, leak2
+        ctx.has_b1, ctx.has_b2 = b1 is not None, b2 is not None
+        ctx.save_for_backward(x, y1, a1, y2, out, w1, w2, g1, g2, m1, s1, m2, s2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, y1, a1, y2, out, w1, w2, g1, g2, m1, s1, m2, s2 = ctx.saved_tensors
+        dout = _f32c(dout)
+        n, C = x.shape
+        dev = x.device
+        L = lib()
+        st = _stream()
+        rb = ctx.rb
+        tr = 1 if ctx.training else 0
+        vec = lambda: torch.empty(C, dtype=torch.float32, device=dev)
+        # BN2 (+ skip + act) backward: dy2, and the skip branch's gradient dres
+        dy2, dres, dg2, dbe2 = torch.empty_like(x), torch.empty_like(x), vec(), vec()
+        check(L.sei_bn_backward(_ptr(y2), _ptr(out), _ptr(dout), n, C, _ptr(g2), _ptr(m2), _ptr(s2), ctx.leak2, tr,
+                                _ptr(dy2), _ptr(dres), _ptr(dg2), _ptr(dbe2), st))
+        dw2 = torch.empty_like(w2)
+        db2 = vec() if ctx.has_b2 else None
+        check(L.sei_conv_backward_weight(rb.h, _ptr(a1), _ptr(dy2), _ptr(dw2), _ptr(db2), C, C, st))
+        da1 = torch.empty_like(x)
+        check(L.sei_conv_backward_input(rb.h, _ptr(dy2), _ptr(w2), _ptr(da1), C, C, st))
+        del dy2
+        dy1, dg1, dbe1 = torch.empty_like(x), vec(), vec()
+        check(L.sei_bn_backward(_ptr(y1), _ptr(a1), _ptr(da1), n, C, _ptr(g1), _ptr(m1), _ptr(s1), ctx.leak1, tr,
+                                _ptr(dy1), None, _ptr(dg1), _ptr(dbe1), st))
+        del da1
+        dw1 = torch.empty_like(w1)
+        db1 = vec() if ctx.has_b1 else None
+        check(L.sei_conv_backward_weight(rb.h, _ptr(x), _ptr(dy1), _ptr(dw1), _ptr(db1), C, C, st))
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            # dX = dres + conv1^T(dy1): the skip gradient seeds the kernel's accumulators
+            check(L.sei_conv_backward_input_accumulate(rb.h, _ptr(dy1), _ptr(w1), _ptr(dres), _ptr(dx), C, C, st))
+        return (dx, None, dw1, db1, dg1, dbe1, None, None, dw2, db2, dg2, dbe2, None, None, None, None, None, None, None)
+
+
+def residual_block_supported(nplanes):
+    """The fused node needs the MFMA conv kernel (planes a multiple of 16, <= 256)."""
+    return nplanes % 16 == 0 and 16 <= nplanes <= 256
+
+
+def residual_block(x, conv1, bn1, conv2, bn2, leak1, leak2):
+    """Fused ResidualBlock on SparseConvNetTensor ``x``: conv1/conv2 are SubmanifoldConvolution modules with equal
+    filter size and nIn == nOut, bn1/bn2 BatchNormalization modules (affine)."""
+    sp = _triple(x.spatial_size)
+    rb = x.metadata.subm_rulebook(sp, conv1.filter_size)
+    out = SparseConvNetTensor(metadata=x.metadata, spatial_size=x.spatial_size)
+    out.features = _ResidualBlock.apply(_f32c(x.features), rb, conv1.weight, conv1.bias, bn1.weight, bn1.bias,
+                                        bn1.running_mean, bn1.running_var, conv2.weight, conv2.bias, bn2.weight, bn2.bias,
+                                        bn2.running_mean, bn2.running_var, bn1.eps, bn1.momentum, bn1.training,
+                                        float(leak1), float(leak2))
+    return out
+
+
 class _Leaky(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, leak):
