@@ -12,6 +12,7 @@ the engine.  There is no CPU fallback.
 """
 import ctypes
 import math
+import weakref
 
 import torch
 from torch import nn
@@ -58,7 +59,10 @@ class Metadata:
         h = ctypes.c_void_p()
         check(lib().sei_metadata_create(ctypes.byref(h)))
         self._h = h
-        self._rulebooks = {}
+        # python-side cache of Rulebook wrappers.  WEAK values: a Rulebook keeps its Metadata alive (autograd
+        # contexts hold Rulebooks), so a strong cache would be a reference cycle and the device memory of every
+        # batch would wait for the cyclic garbage collector; the C side caches the rulebooks themselves.
+        self._rulebooks = weakref.WeakValueDictionary()
 
     def __del__(self):
         h = getattr(self, "_h", None)

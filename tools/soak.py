@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Soak test: many training steps on CHANGING batches (level sizes vary step to step); watches the loss, the
+library's device pool and torch's allocator for growth."""
+import ctypes, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import generate_batch
+B, STEPS = int(sys.argv[1]) if len(sys.argv) > 1 else 16, int(sys.argv[2]) if len(sys.argv) > 2 else 24
+batches = [generate_batch(0, i, B, (900, 900, 900), 50000 - 3000 * (i % 4), "tracks", 16) for i in range(6)]
+import torch
+from sparseeventid_amd import _lib
+from sparseeventid_amd.train import Trainer
+tr = Trainer(image_size=[1, 900, 900, 900])
+lib = _lib.lib()
+held, used = ctypes.c_int64(), ctypes.c_int64()
+t0 = time.time()
+for step in range(STEPS):
+    arr, labels = batches[step % len(batches)]
+    image, lab = tr.stage(tr.to_scn_input(arr), labels)
+    loss, _ = tr.train_step(image, lab)
+    if step % 4 == 3 or step == STEPS - 1:
+        torch.cuda.synchronize()
+        lib.sei_pool_stats(ctypes.byref(held), ctypes.byref(used))
+        print("step %3d loss %.4f  pool held %.2f GB in-use %.2f GB  torch alloc %.2f GB reserved %.2f GB  %.1f s"
+              % (step, float(loss), held.value / 1e9, used.value / 1e9, torch.cuda.memory_allocated() / 1e9,
+                 torch.cuda.memory_reserved() / 1e9, time.time() - t0), flush=True)
+assert torch.isfinite(loss)
+print("soak ok")
