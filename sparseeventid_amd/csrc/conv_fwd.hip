@@ -21,6 +21,21 @@ namespace sei {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Diagnostic build only (make EXTRA=-DSEI_STAMPS; tools/stamps.py): wave 1 of every tile adds the s_memtime
+// ticks it spends in each part of the forward kernel to g_stamps.  The product build compiles none of it.
+#ifdef SEI_STAMPS
+__device__ unsigned long long g_stamps[16];
+#define STAMP_DECL unsigned long long st_t = __builtin_amdgcn_s_memtime(), st_acc[16] = {}
+#define STAMP(i) do { unsigned long long n_ = __builtin_amdgcn_s_memtime(); st_acc[i] += n_ - st_t; st_t = n_; } while (0)
+#define STAMP_ADD(i, v) st_acc[i] += (v)
+#define STAMP_FLUSH do { if (threadIdx.x == 64) { for (int i_ = 0; i_ < 16; i_++) atomicAdd(&g_stamps[i_], st_acc[i_]); } } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_ADD(i, v)
+#define STAMP_FLUSH
+#endif
+
 __device__ inline f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
 __device__ inline void lds_add(float *p, float v) {
@@ -29,7 +44,10 @@ __device__ inline void lds_add(float *p, float v) {
 
 // unconditional load (clamped row) + select: conditional loads make hipcc serialise them with vmcnt(0)
 __device__ inline float4 load_a(const float *__restrict__ X, int src, int CIN, int off) {
-    const int row = src >= 0 ? src : 0;
+    int row = src >= 0 ? src : 0;
+#ifdef SEI_ABLATE_GATHER  // diagnostic: every gather hits the caches (results are wrong, timing only)
+    row &= 1023;
+#endif
     float4 v = *reinterpret_cast<const float4 *>(X + (size_t)row * CIN + off);
     if (src < 0) v = make_float4(0.f, 0.f, 0.f, 0.f);
     return v;
@@ -146,6 +164,7 @@ __global__ __launch_bounds__(256, occ_for(MAXS, NT, SLJ)) void conv_tile_mfma_ke
     float *wbuf = lds + (size_t)TR * ASTRIDE;
     int *seg = reinterpret_cast<int *>(wbuf + 2 * SL * COUT);
 
+    STAMP_DECL;
     for (int i = threadIdx.x; i <= K; i += 256) seg[i] = tile_seg[(size_t)tile * (K + 1) + i];
     {
         // accumulators start from the bias, or from the rows of `init` (Y = init + conv: gradient accumulation)
@@ -203,6 +222,7 @@ __global__ __launch_bounds__(256, occ_for(MAXS, NT, SLJ)) void conv_tile_mfma_ke
                 a_n[m][jj] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         int phase = 0;
+        STAMP(10);
         while (k < K) {
             const int kw = k1 < K ? k1 : k;  // weights to prefetch after the last slice (unused at the very end)
             f32x4 acc[MAXS][NT];
@@ -225,6 +245,7 @@ __global__ __launch_bounds__(256, occ_for(MAXS, NT, SLJ)) void conv_tile_mfma_ke
                     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * MAXS) : "memory");
                 else
                     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                STAMP(0);
                 if (s == 0) {
                     // D[row = 4g+i][col = r16] belongs to rule slot 4g+i.  Rows of one offset are distinct and the
                     // previous offset's updates are behind the barrier: the accumulators START from the tile's
@@ -241,6 +262,7 @@ __global__ __launch_bounds__(256, occ_for(MAXS, NT, SLJ)) void conv_tile_mfma_ke
                         }
                     }
                 }
+                STAMP(1);
                 // prefetch the next phase's weight slice and A fragments while this one computes
                 const bool same_k = s + 1 < NS;
                 stage_slice<PIECES>(W + ((size_t)(same_k ? k : kw) * CIN + (size_t)(same_k ? s + 1 : 0) * SL) * COUT,
@@ -252,6 +274,7 @@ __global__ __launch_bounds__(256, occ_for(MAXS, NT, SLJ)) void conv_tile_mfma_ke
                     for (int jj = 0; jj < SLJ; jj++)
                         a_n[m][jj] = load_a(X, same_k ? ic.row(m) : in1.row(m), CIN, aoff + 16 * jj);
                 const float *wb = wbuf + (size_t)(phase & 1) * SL * COUT + col0;
+                STAMP(2);
                 if (MAXS == 1) {
                     if (ic.ms == 1) compute_phase<NT, SLJ, 1, MAXS, COUT>(wb, a_c, acc, g, r16);
                 } else if (MAXS == 2) {
@@ -266,11 +289,15 @@ __global__ __launch_bounds__(256, occ_for(MAXS, NT, SLJ)) void conv_tile_mfma_ke
                         default: break;
                     }
                 }
+                STAMP(3);
+                STAMP_ADD(8, 1);
+                STAMP_ADD(9, ic.ms * NT * 4 * SLJ);
 #pragma unroll
                 for (int m = 0; m < MAXS; m++)
 #pragma unroll
                     for (int jj = 0; jj < SLJ; jj++) a_c[m][jj] = a_n[m][jj];
                 phase++;
+                STAMP(4);
             }
 #pragma unroll
             for (int m = 0; m < MAXS; m++) {
@@ -284,12 +311,14 @@ __global__ __launch_bounds__(256, occ_for(MAXS, NT, SLJ)) void conv_tile_mfma_ke
                     }
                 }
             }
+            STAMP(5);
             ic = in1;
             in1 = in2;
             k = k1;
             k1 = k2;
             k2 = next_k(k2);
             in2 = load_idx(k2);  // two offsets ahead: its latency never meets a barrier
+            STAMP(6);
         }
     }
     __syncthreads();
@@ -302,6 +331,9 @@ __global__ __launch_bounds__(256, occ_for(MAXS, NT, SLJ)) void conv_tile_mfma_ke
             *reinterpret_cast<float4 *>(Y + (size_t)(row0 + r) * COUT + 4 * v) =
                 *reinterpret_cast<const float4 *>(acc_tile + (size_t)r * ASTRIDE + 4 * v);
     }
+    STAMP(11);
+    STAMP_ADD(7, 1);
+    STAMP_FLUSH;
 }
 
 // Stem-type convolutions (tiny nIn, e.g. 1 -> 32 with 125 offsets): all of W sits in LDS, lane = output
@@ -546,3 +578,14 @@ int conv_forward(const TiledRules &t, const float *X, const float *W, const floa
 }
 
 }  // namespace sei
+
+#ifdef SEI_STAMPS
+extern "C" int sei_debug_stamps(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(sei::g_stamps), sizeof(sei::g_stamps)) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(sei::g_stamps), z, sizeof(z)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif

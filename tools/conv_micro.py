@@ -18,18 +18,27 @@ def main():
     ap.add_argument("--bwd", action="store_true")
     ap.add_argument("--stats", action="store_true")
     ap.add_argument("--kind", default="tracks")
+    ap.add_argument("--dense", type=int, default=0, help="dense D^3 cube per event instead of the DUNE batch (kernel ceiling: no padding, perfect balance)")
     ap.add_argument("--workers", type=int, default=int(os.environ.get("SEI_GEN_WORKERS", "0")) or min(16, os.cpu_count() or 8))
     a = ap.parse_args()
-    from bench import generate_batch
-    arr, _ = generate_batch(0, 0, a.events, (900, 900, 900), 50000, a.kind, a.workers)
     import torch
     import sparseeventid_amd.scn as scn
-    from sparseeventid_amd.data import larcvsparse_to_scnsparse_3d
-    c, f, b = larcvsparse_to_scnsparse_3d(arr)
-    t = scn.InputLayer(3, [900, 900, 900])((torch.from_numpy(c), torch.from_numpy(f).cuda(), b))
-    t.features = torch.randn(t.features.shape[0], 16, device="cuda")
-    for _ in range(a.level):
-        t = scn.Convolution(3, 16, 16, 2, 2, False).cuda()(t)
+    if a.dense:
+        D = a.dense
+        ax = np.arange(D)
+        g3 = np.stack(np.meshgrid(ax, ax, ax, indexing="ij"), -1).reshape(-1, 3)
+        c = np.concatenate([np.concatenate([g3, np.full((len(g3), 1), e)], 1) for e in range(a.events)]).astype(np.int64)
+        f = np.ones((len(c), 1), np.float32)
+        t = scn.InputLayer(3, [D, D, D])((torch.from_numpy(c), torch.from_numpy(f).cuda(), a.events))
+    else:
+        from bench import generate_batch
+        arr, _ = generate_batch(0, 0, a.events, (900, 900, 900), 50000, a.kind, a.workers)
+        from sparseeventid_amd.data import larcvsparse_to_scnsparse_3d
+        c, f, b = larcvsparse_to_scnsparse_3d(arr)
+        t = scn.InputLayer(3, [900, 900, 900])((torch.from_numpy(c), torch.from_numpy(f).cuda(), b))
+        t.features = torch.randn(t.features.shape[0], 16, device="cuda")
+        for _ in range(a.level):
+            t = scn.Convolution(3, 16, 16, 2, 2, False).cuda()(t)
     sp = [int(x) for x in t.spatial_size]
     n = t.features.shape[0]
     x = torch.randn(n, a.cin, device="cuda", requires_grad=a.bwd)
@@ -53,6 +62,23 @@ def main():
                 tot_max += ((subs + U - 1) // U).sum()
             print("  TR=%d U=%d: sub-chunks %d pad-eff %.3f balance %.3f -> combined %.3f" % (
                 TR, U, tot_sub, R / (16 * tot_sub), tot_sub / (U * tot_max), R / (16 * U * tot_max)))
+        # what-if: remainder sub-chunks of an offset split by columns over the 4 waves (halves / quarters)
+        for TR in (128, 64):
+            cost = {"whole": 0.0, "halves": 0.0, "quarters": 0.0}
+            tot_sub = 0
+            hist = np.zeros(17, np.int64)
+            for k in range(27):
+                rows = ro[start[k]:start[k + 1]]
+                cnt = np.bincount(rows // TR, minlength=(n + TR - 1) // TR)
+                subs = (cnt + 15) // 16
+                hist += np.bincount(subs, minlength=17)[:17]
+                q, r = subs // 4, subs % 4
+                tot_sub += subs.sum()
+                cost["whole"] += (q + (r > 0)).sum()
+                cost["halves"] += (q + np.array([0, .5, .5, 1.])[r]).sum()
+                cost["quarters"] += (q + r / 4.0).sum()
+            print("  TR=%d ns histogram %s" % (TR, hist[:10].tolist()))
+            print("  TR=%d balance: " % TR + "  ".join("%s %.3f" % (kk, tot_sub / (4 * v)) for kk, v in cost.items()))
     g = torch.randn_like(out.features)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for name, fn in (("fwd", lambda: conv(t)),) + ((("fwd+bwd", lambda: conv(t).features.backward(g)),) if a.bwd else ()):

@@ -15,14 +15,17 @@ for _ in range(lvl):
 t.features = torch.randn(t.features.shape[0], c, device="cuda")
 conv = scn.SubmanifoldConvolution(3, c, c, 3, True).cuda()
 conv(t); torch.cuda.synchronize()
-l = ctypes.CDLL(_lib.LIB_PATH)
-buf = (ctypes.c_ulonglong * 8)()
+l = ctypes.CDLL(_lib.LIB_PATH)   # diagnostic build: make -C sparseeventid_amd/csrc EXTRA=-DSEI_STAMPS
+buf = (ctypes.c_ulonglong * 16)()
 l.sei_debug_stamps(buf, 1)
 conv(t); torch.cuda.synchronize()
 l.sei_debug_stamps(buf, 1)
 v = np.array(list(buf), dtype=np.float64)
-names = ["other", "barrier wait", "issue stage+gathers", "MFMA phase", "wait A + copy", "scatter", "tail", "tiles"]
-tot = v[:7].sum()
-print("level %d C=%d: per-tile wave-1 cycles (s_memtime ticks), share" % (lvl, c))
-for n, x in zip(names, v):
-    print("  %-22s %12.0f  %5.1f%%" % (n, x / max(v[7], 1), 100 * x / tot if n != "tiles" else 0))
+names = {0: "wait loads + barrier", 1: "accumulators <- LDS tile", 2: "issue W slice DMA + gathers", 3: "MFMA phase",
+         4: "A register rotate", 5: "accumulators -> LDS tile", 6: "next offset bookkeeping", 10: "prologue", 11: "epilogue"}
+tot = sum(v[i] for i in names)
+print("level %d C=%d: wave 1, s_memtime ticks per tile (%d tiles), share" % (lvl, c, v[7]))
+for i, n in names.items():
+    print("  %-30s %10.1f  %5.1f%%" % (n, v[i] / max(v[7], 1), 100 * v[i] / tot))
+print("  phases / tile %.1f; MFMA issued / phase %.1f; ticks per MFMA in the MFMA phase %.3f" % (
+    v[8] / v[7], v[9] / max(v[8], 1), v[3] / max(v[9], 1)))
