@@ -138,7 +138,11 @@ def input_layer(coords, features, batch_size, spatial_size, mode=3):
     if isinstance(coords, torch.Tensor):
         coords = coords.detach().cpu().numpy()
     row_of, first, last, cnt, oc = input_rows(coords, spatial_size, batch_size)
-    feats = features.detach().cpu().float() if not features.requires_grad else features
+    # fp32 like the reference; a float64 feature tensor is kept (tests use an fp64 run of this oracle to
+    # tell which fp32 side carries the rounding error when the two disagree near the tolerance)
+    feats = features if features.requires_grad else features.detach().cpu()
+    if feats.dtype != torch.float64 and not features.requires_grad:
+        feats = feats.float()
     nu = oc.shape[0]
     if mode in (0, 2):
         out = feats.index_select(0, torch.from_numpy(first.astype(np.int64)))
@@ -148,7 +152,7 @@ def input_layer(coords, features, batch_size, spatial_size, mode=3):
         out = torch.zeros(nu, feats.shape[1], dtype=feats.dtype).index_add(
             0, torch.from_numpy(row_of.astype(np.int64)), feats)
         if mode == 4:
-            out = out / torch.from_numpy(cnt.astype(np.float32))[:, None]
+            out = out / torch.from_numpy(cnt.astype(np.float32)).to(out.dtype)[:, None]
     return OracleTensor(out, oc, _triple(spatial_size), batch_size)
 
 

@@ -8,11 +8,12 @@
 //   LDS by LDS-DMA in slices of 16/32 input planes (double buffered, ONE barrier per slice) and is
 //   shared by all waves; src feature rows are gathered straight into MFMA A-operand registers one
 //   phase ahead (float4 per lane, 64 B per rule row and step; rule indices two offsets ahead),
-//   multiplied with v_mfma_f32_16x16x4_f32 (exact fp32), and the 16xN results are added into the LDS
-//   tile (ds_add_f32).  Rows of one k are distinct and the k-phases are barrier-separated, so the
-//   summation order is fixed: run-to-run deterministic, no global atomics; every dst row is written
-//   to HBM exactly once.  Tiles are sized so that 2-6 workgroups share a CU: the barrier / gather
-//   latency of one workgroup is covered by its neighbours' MFMAs.
+//   multiplied with v_mfma_f32_16x16x4_f32 (exact fp32) into zero-initialised accumulators, and after the
+//   offset's last slice the 16xN partial sums are added into the LDS tile by a plain read-modify-write.
+//   Rows of one k are distinct and the k-phases are barrier-separated, so the summation order is fixed
+//   (and the same as the reference's per-offset  out[rows] += in[rows] @ W[k]): run-to-run deterministic,
+//   no atomics; every dst row is written to HBM exactly once.  Tiles are sized so that 2-6 workgroups share
+//   a CU: the barrier / gather latency of one workgroup is covered by its neighbours' MFMAs.
 #include "common.h"
 
 #include <stdlib.h>
@@ -127,8 +128,8 @@ struct RuleIdx {
 
 constexpr int occ_for(int maxs, int nt, int slj) {
     // waves per SIMD the register allocator should aim for (LDS decides the rest):
-    // accumulators + two A fragment sets + B values + ~80 registers of addressing / indices
-    const int est = maxs * nt * 4 + 2 * maxs * slj * 4 + nt + 80;
+    // accumulators + saved tile values + two A fragment sets + B values + ~80 registers of addressing / indices
+    const int est = maxs * nt * 4 + nt * 4 + 2 * maxs * slj * 4 + nt + 80;
     return est <= 132 ? 4 : (est <= 165 ? 3 : (est <= 250 ? 2 : 1));
 }
 
@@ -247,20 +248,11 @@ __global__ __launch_bounds__(256, occ_for(MAXS, NT, SLJ)) void conv_tile_mfma_ke
                     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 STAMP(0);
                 if (s == 0) {
-                    // D[row = 4g+i][col = r16] belongs to rule slot 4g+i.  Rows of one offset are distinct and the
-                    // previous offset's updates are behind the barrier: the accumulators START from the tile's
-                    // current values (plain LDS reads, latency hidden under the loads issued next) and are
-                    // simply written back after the last slice -- no atomics (LDS float atomics cost ~150
-                    // cycles per wave-instruction on gfx950), no separate add, fixed summation order.
+                    // the offset's products are summed from zero (see the write-back below)
 #pragma unroll
-                    for (int m = 0; m < MAXS; m++) {
-                        if (m < ic.ms) {  // wave-uniform: one branch per sub-chunk, loads inside are unconditional
+                    for (int m = 0; m < MAXS; m++)
 #pragma unroll
-                            for (int n = 0; n < NT; n++)
-#pragma unroll
-                                for (int i = 0; i < 4; i++) acc[m][n][i] = prow[m][i][16 * n];
-                        }
-                    }
+                        for (int n = 0; n < NT; n++) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
                 STAMP(1);
                 // prefetch the next phase's weight slice and A fragments while this one computes
@@ -299,14 +291,25 @@ __global__ __launch_bounds__(256, occ_for(MAXS, NT, SLJ)) void conv_tile_mfma_ke
                 phase++;
                 STAMP(4);
             }
+            // D[row = 4g+i][col = r16] belongs to rule slot 4g+i.  Rows of one offset are distinct and the previous
+            // offset's updates are behind the barrier:  tile = tile + partial  is a plain LDS read-modify-write --
+            // no atomics (LDS float atomics cost ~150 cycles per wave-instruction on gfx950), fixed summation
+            // order, and the fp32 chains stay short (nIn/4 MFMA steps, then one add per offset) like the
+            // reference's per-offset  out[rows] += in[rows] @ W[k].  All reads of a sub-chunk are issued before
+            // its adds (one LDS latency per sub-chunk and offset, covered by the CU's other waves).
 #pragma unroll
             for (int m = 0; m < MAXS; m++) {
-                if (m < ic.ms) {
+                if (m < ic.ms) {  // wave-uniform: one branch per sub-chunk, loads inside are unconditional
+                    f32x4 tv[NT];
+#pragma unroll
+                    for (int n = 0; n < NT; n++)
+#pragma unroll
+                        for (int i = 0; i < 4; i++) tv[n][i] = prow[m][i][16 * n];
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
                         if (4 * g + i < nv[m]) {
 #pragma unroll
-                            for (int n = 0; n < NT; n++) prow[m][i][16 * n] = acc[m][n][i];
+                            for (int n = 0; n < NT; n++) prow[m][i][16 * n] = tv[n][i] + acc[m][n][i];
                         }
                     }
                 }
