@@ -317,8 +317,9 @@ int sei_conv_forward(sei_rulebook_t *rb, const float *X, const float *W, const f
     if (!rb) SEI_FAIL("null rulebook");
     hipStream_t st = (hipStream_t)stream;
     const TiledRules *t;
-    SEI_TRY(get_tiled(rb, false, conv_tile_rows(nIn, nOut), &t, st));
-    const int cgp = conv_col_group(nIn, nOut);
+    const int64_t n_dst = rb->lout ? rb->lout->n : 0;
+    SEI_TRY(get_tiled(rb, false, conv_tile_rows(nIn, nOut, n_dst), &t, st));
+    const int cgp = conv_col_group(nIn, nOut, n_dst);
     if (cgp == 0) {
         ProfScope ps(PROF_CONV_FWD, st, 2.0 * t->n_rules * nIn * nOut, conv_bytes(*t, nIn, nOut));
         return conv_forward(*t, X, W, bias, Y, nIn, nOut, st);
@@ -326,7 +327,7 @@ int sei_conv_forward(sei_rulebook_t *rb, const float *X, const float *W, const f
     // the MFMA kernel reads B operands with wide LDS loads from column-permuted weights (tiny copy, <= 4 MB)
     float *Wp;
     SEI_TRY(pool_alloc_t(&Wp, (size_t)t->K * nIn * nOut));
-    int rc = conv_transform_weights(W, Wp, t->K, nIn, nOut, false, false, cgp, st);
+    int rc = conv_transform_weights(W, Wp, t->K, nIn, nOut, false, false, cgp, conv_col_blocks(nIn, nOut, n_dst), st);
     if (!rc) {
         ProfScope ps(PROF_CONV_FWD, st, 2.0 * t->n_rules * nIn * nOut, conv_bytes(*t, nIn, nOut));
         rc = conv_forward(*t, X, Wp, bias, Y, nIn, nOut, st);
@@ -341,13 +342,15 @@ static int conv_backward_input_impl(sei_rulebook_t *rb, const float *dY, const f
     hipStream_t st = (hipStream_t)stream;
     const TiledRules *t;
     // roles swap: contraction over nOut, result has nIn columns
-    SEI_TRY(get_tiled(rb, true, conv_tile_rows(nOut, nIn), &t, st));
+    const int64_t n_dst = rb->lin ? rb->lin->n : 0;
+    SEI_TRY(get_tiled(rb, true, conv_tile_rows(nOut, nIn, n_dst), &t, st));
     if (dX_init && (!conv_supports_init(nOut, nIn) || t->n_sub == 0))
         SEI_FAIL("conv_backward_input_accumulate: not supported for these plane counts");
     float *Wt;
     SEI_TRY(pool_alloc_t(&Wt, (size_t)t->K * nIn * nOut));
     // Wt[k'][co][ci] = W[K-1-k' (submanifold mirror) or k'][ci][co], columns (ci) permuted for the kernel
-    int rc = conv_transform_weights(W, Wt, t->K, nIn, nOut, true, rb->submanifold, conv_col_group(nOut, nIn), st);
+    int rc = conv_transform_weights(W, Wt, t->K, nIn, nOut, true, rb->submanifold, conv_col_group(nOut, nIn, n_dst),
+                                    conv_col_blocks(nOut, nIn, n_dst), st);
     if (!rc) {
         ProfScope ps(PROF_CONV_BWD_IN, st, 2.0 * t->n_rules * nIn * nOut, conv_bytes(*t, nOut, nIn));
         rc = conv_forward(*t, dY, Wt, nullptr, dX, nOut, nIn, st, dX_init);

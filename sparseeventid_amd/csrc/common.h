@@ -166,14 +166,15 @@ int build_strided_level(sei_metadata *m, Level *lin, const int32_t size[3], cons
                         hipStream_t st);
 int export_rules(const TiledRules &t, int64_t *start_host, int32_t *rin, int32_t *rout, hipStream_t st);
 // conv.hip
-int conv_tile_rows(int nIn, int nOut);  // tile size the forward kernel wants for these plane counts
+int conv_tile_rows(int nIn, int nOut, int64_t n_dst);  // tile size the forward kernel wants for these plane / row counts
 int conv_forward(const TiledRules &t, const float *X, const float *W, const float *bias, float *Y, int nIn, int nOut,
                  hipStream_t st, const float *init = nullptr);
 bool conv_supports_init(int nIn, int nOut);
-int conv_col_group(int nIn, int nOut);
+int conv_col_group(int nIn, int nOut, int64_t n_dst);
+int conv_col_blocks(int nIn, int nOut, int64_t n_dst);  // > 1: weights stored as [block][K][nIn][nOut/blocks] (one workgroup per column block)
 // Wout[k][r][perm(c)]: transpose=false: rows=nIn, cols=nOut (forward); transpose=true: Wout[k][co][perm(ci)] = W[ks][ci][co]
 // with ks = flip ? K-1-k : k (dX).  perm = column permutation inside groups of `col_group` columns (0 = identity).
-int conv_transform_weights(const float *W, float *Wout, int K, int nIn, int nOut, bool transpose, bool flip, int col_group,
+int conv_transform_weights(const float *W, float *Wout, int K, int nIn, int nOut, bool transpose, bool flip, int col_group, int blocks,
                            hipStream_t st);
 int conv_backward_weight(const TiledRules &t, const float *X, const float *dY, float *dW, int nIn, int nOut,
                          hipStream_t st);

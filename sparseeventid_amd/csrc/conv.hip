@@ -46,8 +46,18 @@ __device__ inline int permute_col(int c, int width) {
     return grp * width + pos;
 }
 
+// destination index of element (row, col) of offset ks in the kernel's weight layout: [K][rows][cols] with the
+// columns of every group permuted, or (blocks > 1) [block][K][rows][cols / blocks] so that each column block is
+// a contiguous panel for the workgroups that own it
+__device__ inline size_t weight_index(int ks, int row, int col, int K, int rows, int cols, int col_group, int blocks) {
+    const int pc = permute_col(col, col_group);
+    if (blocks <= 1) return ((size_t)ks * rows + row) * cols + pc;
+    const int w = cols / blocks, b = pc / w;
+    return (((size_t)b * K + ks) * rows + row) * w + (pc - b * w);
+}
+
 __global__ void transform_weights_kernel(const float *__restrict__ W, float *__restrict__ Wout, int K, int nIn, int nOut,
-                                         int transpose, int flip, int col_group) {
+                                         int transpose, int flip, int col_group, int blocks) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t per = (int64_t)nIn * nOut;
     if (t >= K * per) return;
@@ -57,16 +67,16 @@ __global__ void transform_weights_kernel(const float *__restrict__ W, float *__r
     int ks = flip ? K - 1 - k : k;              // destination offset index
     float v = W[t];
     if (transpose)
-        Wout[(size_t)ks * per + (size_t)co * nIn + permute_col(ci, col_group)] = v;
+        Wout[weight_index(ks, co, ci, K, nOut, nIn, col_group, blocks)] = v;
     else
-        Wout[(size_t)ks * per + (size_t)ci * nOut + permute_col(co, col_group)] = v;
+        Wout[weight_index(ks, ci, co, K, nIn, nOut, col_group, blocks)] = v;
 }
 
 int conv_transform_weights(const float *W, float *Wout, int K, int nIn, int nOut, bool transpose, bool flip, int col_group,
-                           hipStream_t st) {
+                           int blocks, hipStream_t st) {
     int64_t tot = (int64_t)K * nIn * nOut;
     transform_weights_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, st>>>(W, Wout, K, nIn, nOut, transpose ? 1 : 0,
-                                                                           flip ? 1 : 0, col_group);
+                                                                           flip ? 1 : 0, col_group, blocks);
     SEI_LAUNCH_CHECK();
     return 0;
 }

@@ -17,6 +17,7 @@
 #include "common.h"
 
 #include <stdlib.h>
+#include <string.h>
 
 namespace sei {
 
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(256, occ_for(MAXS, NT, SLJ)) void conv_tile_mfma_ke
     const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ Y,
     const int32_t *__restrict__ tile_sub_start, const int32_t *__restrict__ tile_seg,
     const int32_t *__restrict__ sub_src, const uint8_t *__restrict__ sub_dst, int64_t n_dst, int K, int CIN, int n_tiles,
-    const float *__restrict__ init) {
+    const float *__restrict__ init, int ldy, int blocks) {
     extern __shared__ float lds[];
     constexpr int U = 4 / CS;  // units (groups of CS waves) dealing sub-chunks
     constexpr int TR = 16 * MAXS * U;
@@ -154,9 +155,15 @@ __global__ __launch_bounds__(256, occ_for(MAXS, NT, SLJ)) void conv_tile_mfma_ke
     constexpr int ASTRIDE = COUT + APAD;     // accumulator row stride (floats)
     // workgroups are dealt round-robin to the 8 XCDs: give every XCD one contiguous run of tiles so that
     // neighbouring tiles (which gather many of the same src rows) share that XCD's L2 (speed only)
-    const int per_xcd = (n_tiles + 7) >> 3;
-    const int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (tile >= n_tiles) return;
+    // (blocks > 1: the COUT columns handled here are one of `blocks` column blocks of the ldy-wide output; the
+    // blocks of a tile are neighbours in this order, they gather the same src rows)
+    const int per_xcd = (n_tiles * blocks + 7) >> 3;
+    const int vid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (vid >= n_tiles * blocks) return;
+    const int tile = vid / blocks, cblk = vid - tile * blocks;
+    W += (size_t)cblk * K * CIN * COUT;
+    if (bias) bias += cblk * COUT;
+    const int ycol0 = cblk * COUT;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int unit = wave / CS, cg = wave - unit * CS;
     const int col0 = cg * NC;
@@ -174,7 +181,7 @@ __global__ __launch_bounds__(256, occ_for(MAXS, NT, SLJ)) void conv_tile_mfma_ke
         for (int idx = threadIdx.x; idx < TR * V; idx += 256) {
             int r = idx / V, v = idx - r * V;
             float4 b = bias ? *reinterpret_cast<const float4 *>(bias + 4 * v) : make_float4(0.f, 0.f, 0.f, 0.f);
-            if (init && row0i + r < n_dst) b = *reinterpret_cast<const float4 *>(init + (size_t)(row0i + r) * COUT + 4 * v);
+            if (init && row0i + r < n_dst) b = *reinterpret_cast<const float4 *>(init + (size_t)(row0i + r) * ldy + ycol0 + 4 * v);
             *reinterpret_cast<float4 *>(acc_tile + (size_t)r * ASTRIDE + 4 * v) = b;
         }
     }
@@ -331,7 +338,7 @@ __global__ __launch_bounds__(256, occ_for(MAXS, NT, SLJ)) void conv_tile_mfma_ke
     for (int idx = threadIdx.x; idx < TR * V; idx += 256) {
         int r = idx / V, v = idx - r * V;
         if (row0 + r < n_dst)
-            *reinterpret_cast<float4 *>(Y + (size_t)(row0 + r) * COUT + 4 * v) =
+            *reinterpret_cast<float4 *>(Y + (size_t)(row0 + r) * ldy + ycol0 + 4 * v) =
                 *reinterpret_cast<const float4 *>(acc_tile + (size_t)r * ASTRIDE + 4 * v);
     }
     STAMP(11);
@@ -441,7 +448,7 @@ __global__ void fill_bias_kernel(float *Y, int64_t n, int C, const float *bias) 
 
 struct FwdPlan {
     bool mfma;
-    int nt, cs, slj, maxs, tile_rows;
+    int nt, cs, slj, maxs, tile_rows, blocks;
     size_t lds_bytes;
 };
 
@@ -449,36 +456,59 @@ static size_t fwd_lds(int tile_rows, int nOut, int slj, int K) {
     return ((size_t)tile_rows * (nOut + APAD) + 2 * 16 * slj * nOut) * sizeof(float) + (K + 1) * sizeof(int);
 }
 
-// SEI_FWD_PLAN="maxs,cs,slj" overrides the default tiling (kernel experiments only)
-static bool env_plan(int nOut, int *maxs, int *cs, int *slj) {
-    const char *e = getenv("SEI_FWD_PLAN");  // "maxs,cs,slj,nOut"
-    if (!e) return false;
-    int no = 0;
-    return sscanf(e, "%d,%d,%d,%d", maxs, cs, slj, &no) == 4 && no == nOut;
+// SEI_FWD_PLAN="maxs,cs,slj,nOut,blocks[;...]" overrides the default tiling of the layers with that nOut
+// (kernel experiments only)
+static bool env_plan(int nOut, int *maxs, int *cs, int *slj, int *blocks) {
+    const char *e = getenv("SEI_FWD_PLAN");
+    while (e && *e) {
+        int no = 0;
+        *blocks = 1;
+        const int got = sscanf(e, "%d,%d,%d,%d,%d", maxs, cs, slj, &no, blocks);
+        if (got >= 4 && no == nOut) {
+            if (got == 4) *blocks = 1;
+            return true;
+        }
+        e = strchr(e, ';');
+        if (e) e++;
+    }
+    return false;
 }
 
-static FwdPlan plan_forward(int nIn, int nOut, int K) {
+static FwdPlan plan_forward(int nIn, int nOut, int K, int64_t n_dst) {
     FwdPlan p{};
     p.mfma = (nIn % 16 == 0) && (nOut % 16 == 0) && nIn >= 16 && nOut <= 256;
     if (p.mfma) {
-        // the tile size depends on nOut only (the rulebook variant is chosen from it)
-        if (nOut <= 96) {
-            p.maxs = 2; p.cs = 1;   // 128-row tiles
-        } else {
-            p.maxs = 1; p.cs = 1;   // 64-row tiles, wide accumulators
-        }
-        p.slj = (nIn % 32 == 0) ? 2 : 1;
-        int em, ec, es;
-        const bool forced = env_plan(nOut, &em, &ec, &es);
-        if (forced) {
-            if ((nOut / 16) % ec == 0 && em >= 1 && em <= 4 && (ec == 1 || ec == 2)) {
-                p.maxs = em; p.cs = ec;
-                if (es == 1 || (es == 2 && nIn % 32 == 0)) p.slj = es;
+        // The tiling depends on nOut (and, for the tile height of wide layers, on the row count).
+        // nOut <= 96: 128-row tiles, one workgroup owns all columns.  Wider: one workgroup per (tile, column
+        // block) of <= 4 column tiles -- the LDS tile and the weight slices shrink with the block, so 128-row
+        // tiles fit again and 3-6 workgroups share a CU; the src rows are gathered once per block, and the
+        // blocks of a tile run back to back on one XCD and find them in its L2.  Measured at 64 events
+        // (profiles/r01_conv_fwd_column_blocks.log): C=128 67 -> 80, C=160 53 -> 72, C=192 51 -> 64 TFLOP/s.
+        const int tiles = nOut / 16;
+        p.cs = 1; p.maxs = 2; p.blocks = 1;
+        if (nOut > 96) {
+            int nt = 1;
+            for (int c = 2; c <= 4; c++)
+                if (tiles % c == 0) nt = c;
+            if (nt > 1) {
+                p.blocks = tiles / nt;
+                if (n_dst < 100000) p.maxs = 1;   // small levels: 64-row tiles fill the chip better
+            } else {
+                p.maxs = 1;                        // 7, 11, 13 column tiles: undivided, 64-row tiles
             }
         }
-        p.nt = nOut / 16 / p.cs;
+        p.slj = (nIn % 32 == 0) ? 2 : 1;
+        int em, ec, es, eb;
+        if (env_plan(nOut, &em, &ec, &es, &eb)) {
+            if (tiles % ec == 0 && em >= 1 && em <= 4 && (ec == 1 || ec == 2)) {
+                p.maxs = em; p.cs = ec; p.blocks = 1;
+                if (es == 1 || (es == 2 && nIn % 32 == 0)) p.slj = es;
+                if (eb >= 1 && ec == 1 && tiles % eb == 0) p.blocks = eb;
+            }
+        }
+        p.nt = tiles / p.cs / p.blocks;
         p.tile_rows = 16 * p.maxs * (4 / p.cs);
-        p.lds_bytes = fwd_lds(p.tile_rows, nOut, p.slj, K);
+        p.lds_bytes = fwd_lds(p.tile_rows, nOut / p.blocks, p.slj, K);
         if (p.lds_bytes > 160 * 1024) p.mfma = false;
     }
     if (!p.mfma) {
@@ -488,13 +518,18 @@ static FwdPlan plan_forward(int nIn, int nOut, int K) {
     return p;
 }
 
-int conv_tile_rows(int nIn, int nOut) { return plan_forward(nIn, nOut, 27).tile_rows; }
+int conv_tile_rows(int nIn, int nOut, int64_t n_dst) { return plan_forward(nIn, nOut, 27, n_dst).tile_rows; }
 
 // column-group width (floats) whose columns the forward kernel expects permuted; 0 = generic kernel, no permutation
-bool conv_supports_init(int nIn, int nOut) { return plan_forward(nIn, nOut, 27).mfma; }
+bool conv_supports_init(int nIn, int nOut) { return plan_forward(nIn, nOut, 27, 0).mfma; }
 
-int conv_col_group(int nIn, int nOut) {
-    FwdPlan p = plan_forward(nIn, nOut, 27);
+int conv_col_blocks(int nIn, int nOut, int64_t n_dst) {
+    FwdPlan p = plan_forward(nIn, nOut, 27, n_dst);
+    return p.mfma ? p.blocks : 1;
+}
+
+int conv_col_group(int nIn, int nOut, int64_t n_dst) {
+    FwdPlan p = plan_forward(nIn, nOut, 27, n_dst);
     return p.mfma ? p.nt * 16 : 0;
 }
 
@@ -507,8 +542,9 @@ static int launch_mfma(const TiledRules &t, const FwdPlan &p, const float *X, co
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    conv_tile_mfma_kernel<NT, CS, SLJ, MAXS><<<((t.n_tiles + 7) / 8) * 8, 256, p.lds_bytes, st>>>(
-        X, W, bias, Y, t.tile_sub_start, t.tile_seg, t.sub_src, t.sub_dst, t.n_dst, t.K, nIn, t.n_tiles, init);
+    conv_tile_mfma_kernel<NT, CS, SLJ, MAXS><<<((t.n_tiles * p.blocks + 7) / 8) * 8, 256, p.lds_bytes, st>>>(
+        X, W, bias, Y, t.tile_sub_start, t.tile_seg, t.sub_src, t.sub_dst, t.n_dst, t.K, nIn, t.n_tiles, init,
+        NT * CS * 16 * p.blocks, p.blocks);
     SEI_LAUNCH_CHECK();
     return 0;
 }
@@ -528,13 +564,15 @@ int conv_forward(const TiledRules &t, const float *X, const float *W, const floa
         SEI_LAUNCH_CHECK();
         return 0;
     }
-    FwdPlan p = plan_forward(nIn, nOut, t.K);
+    FwdPlan p = plan_forward(nIn, nOut, t.K, t.n_dst);
     if (init && (!p.mfma || t.n_sub == 0)) SEI_FAIL("conv_forward: init is only supported by the MFMA kernel");
     if (p.tile_rows != t.tile_rows) SEI_FAIL("conv_forward: rulebook tile size does not match the kernel plan");
     if (p.mfma) {
         // default plans
         FWD_BOTH_SLJ(1, 1, 2) FWD_BOTH_SLJ(2, 1, 2) FWD_BOTH_SLJ(3, 1, 2) FWD_BOTH_SLJ(4, 1, 2) FWD_BOTH_SLJ(5, 1, 2)
         FWD_BOTH_SLJ(6, 1, 2)
+        FWD_BOTH_SLJ(1, 1, 1) FWD_BOTH_SLJ(2, 1, 1) FWD_BOTH_SLJ(3, 1, 1) FWD_BOTH_SLJ(4, 1, 1) FWD_BOTH_SLJ(5, 1, 1)
+        FWD_BOTH_SLJ(6, 1, 1)
         FWD_BOTH_SLJ(7, 1, 1) FWD_BOTH_SLJ(8, 1, 1) FWD_BOTH_SLJ(9, 1, 1) FWD_BOTH_SLJ(10, 1, 1) FWD_BOTH_SLJ(11, 1, 1)
         FWD_BOTH_SLJ(12, 1, 1) FWD_BOTH_SLJ(13, 1, 1) FWD_BOTH_SLJ(14, 1, 1) FWD_BOTH_SLJ(15, 1, 1) FWD_BOTH_SLJ(16, 1, 1)
         // alternates reachable through SEI_FWD_PLAN (kernel experiments)
@@ -542,6 +580,7 @@ int conv_forward(const TiledRules &t, const float *X, const float *W, const floa
         FWD_CASE(2, 1, 2, 1) FWD_CASE(4, 1, 2, 1) FWD_CASE(6, 1, 2, 1) FWD_CASE(2, 1, 2, 3) FWD_CASE(4, 1, 2, 3)
         FWD_CASE(4, 2, 2, 2) FWD_CASE(5, 2, 2, 2) FWD_CASE(6, 2, 2, 2) FWD_CASE(3, 2, 2, 2)
         FWD_CASE(4, 2, 2, 4) FWD_CASE(5, 2, 2, 4) FWD_CASE(6, 2, 2, 4) FWD_CASE(3, 2, 2, 4) FWD_CASE(2, 2, 2, 4) FWD_CASE(1, 2, 2, 4)
+        FWD_CASE(3, 1, 2, 3) FWD_CASE(3, 1, 2, 4) FWD_CASE(5, 1, 2, 1) FWD_CASE(3, 1, 2, 1) FWD_CASE(5, 1, 1, 1) FWD_CASE(3, 1, 1, 1) FWD_CASE(1, 1, 2, 1) FWD_CASE(1, 1, 1, 1)
         FWD_CASE(8, 1, 2, 2) FWD_CASE(4, 2, 1, 2) FWD_CASE(5, 2, 1, 2) FWD_CASE(6, 2, 1, 2)
         SEI_FAIL("conv_forward: no MFMA instantiation for this plan");
     }

@@ -105,3 +105,33 @@ def test_125_offset_filter_on_the_mfma_path():
     oo.features.backward(g)
     assert rel_err(out.features, oo.features) < 1e-4
     assert rel_err(conv.weight.grad, W.grad) < 1e-4 and rel_err(f.grad, fo.grad) < 1e-4
+
+
+@pytest.mark.parametrize("ci,co", [(128, 128), (160, 160), (96, 192)])
+def test_wide_layers_on_a_large_level(ci, co):
+    """>= 100 000 dst rows switch the wide layers (nOut > 96) to 128-row tiles with one workgroup per
+    (tile, column block): forward, dX (roles of ci / co swapped) and dW against the oracle."""
+    import sparseeventid_amd.scn as scn
+    from tests.util import random_cloud
+    sp, B = [56, 56, 56], 2
+    coords, _ = random_cloud(31, B, sp, 52000, 1)
+    n = len(coords)
+    assert n >= 100000
+    feats = np.random.default_rng(8).standard_normal((n, ci)).astype(np.float32)
+    f = torch.from_numpy(feats).cuda().requires_grad_(True)
+    t = scn.InputLayer(3, sp)((torch.from_numpy(coords), f, B))
+    assert t.features.shape[0] == n
+    conv = scn.SubmanifoldConvolution(3, ci, co, 3, True).cuda()
+    with torch.no_grad():
+        conv.bias.normal_()
+    out = conv(t)
+    g = torch.randn(out.features.shape, generator=torch.Generator().manual_seed(5))
+    out.features.backward(g.cuda())
+    torch.set_num_threads(16)
+    fo = torch.from_numpy(feats).requires_grad_(True)
+    W, b = conv.weight.detach().cpu().requires_grad_(True), conv.bias.detach().cpu().requires_grad_(True)
+    oo = scn_cpu.subm_conv(scn_cpu.input_layer(coords, fo, B, sp), W, b, [3, 3, 3])
+    oo.features.backward(g)
+    assert rel_err(out.features, oo.features) < 1e-4
+    assert rel_err(f.grad, fo.grad) < 1e-4
+    assert rel_err(conv.weight.grad, W.grad) < 1e-4 and rel_err(conv.bias.grad, b.grad) < 1e-4
