@@ -147,7 +147,37 @@ struct DwOps {
     int any;  // wave-uniform: some slot of this step holds a rule
 };
 
-// operands of MFMA step q (rules 4q..4q+3 of the sub-chunk): lane (g, r16) holds X[src_g][ci0+16m+r16], dY[dst_g][16n+r16]
+// Operand values of T 16-channel tiles for one rule row, with as few (wide) loads as possible: the tiles of a
+// group of 4 (2) interleave their channels -- tile j of the group, row/column r  <->  channel 4r+j (2r+j) -- so
+// lane r16 finds the values of 4 (2) tiles in ONE global_load_dwordx4 (dwordx2).  dw_chan is the inverse map.
+template <int T>
+__device__ __forceinline__ void dw_load_vec(const float *__restrict__ p, int r16, bool ok, float (&o)[T]) {
+    constexpr int B4 = T / 4, REM = T % 4;
+#pragma unroll
+    for (int q = 0; q < B4; q++) {
+        const float4 v = *reinterpret_cast<const float4 *>(p + 64 * q + 4 * r16);
+        o[4 * q + 0] = ok ? v.x : 0.f; o[4 * q + 1] = ok ? v.y : 0.f;
+        o[4 * q + 2] = ok ? v.z : 0.f; o[4 * q + 3] = ok ? v.w : 0.f;
+    }
+    if (REM >= 2) {
+        const float2 v = *reinterpret_cast<const float2 *>(p + 64 * B4 + 2 * r16);
+        o[4 * B4 + 0] = ok ? v.x : 0.f; o[4 * B4 + 1] = ok ? v.y : 0.f;
+    }
+    if (REM == 1) { const float v = p[64 * B4 + r16]; o[4 * B4] = ok ? v : 0.f; }
+    if (REM == 3) { const float v = p[64 * B4 + 32 + r16]; o[4 * B4 + 2] = ok ? v : 0.f; }
+}
+
+template <int T>
+__device__ __forceinline__ int dw_chan(int t, int r) {  // channel (relative to the block) of row / column r of tile t
+    constexpr int B4 = T / 4, REM = T % 4;
+    if (t < 4 * B4) return 64 * (t / 4) + 4 * r + (t % 4);
+    const int t2 = t - 4 * B4;
+    if (REM >= 2 && t2 < 2) return 64 * B4 + 2 * r + t2;
+    return 64 * B4 + (REM == 3 ? 32 : 0) + r;
+}
+
+// operands of MFMA step q (rules 4q..4q+3 of the sub-chunk): lane (g, r16) holds X[src_g][ci0 + dw_chan<MT>(m, r16)],
+// dY[dst_g][dw_chan<NT>(n, r16)]
 template <int MT, int NT>
 __device__ __forceinline__ DwOps<MT, NT> dw_load_ops(const DwItem &it, int q, int g, int r16,
                                                      const float *__restrict__ X, const float *__restrict__ dY, int CIN,
@@ -156,18 +186,8 @@ __device__ __forceinline__ DwOps<MT, NT> dw_load_ops(const DwItem &it, int q, in
     const int src = __shfl(it.src, 4 * q + g);
     const int64_t drow = __shfl(it.drow, 4 * q + g);
     const bool ok = src >= 0;
-    const float *xr = X + (size_t)(ok ? src : 0) * CIN + ci0 + r16;
-    const float *yr = dY + (size_t)(ok ? drow : 0) * COUT + r16;
-#pragma unroll
-    for (int m = 0; m < MT; m++) {
-        float v = xr[16 * m];
-        o.a[m] = ok ? v : 0.f;
-    }
-#pragma unroll
-    for (int n = 0; n < NT; n++) {
-        float v = yr[16 * n];
-        o.b[n] = ok ? v : 0.f;
-    }
+    dw_load_vec<MT>(X + (size_t)(ok ? src : 0) * CIN + ci0, r16, ok, o.a);
+    dw_load_vec<NT>(dY + (size_t)(ok ? drow : 0) * COUT, r16, ok, o.b);
     o.any = __any(ok);
     return o;
 }
@@ -235,7 +255,7 @@ __global__ __launch_bounds__(256) void conv_dw_mfma_kernel(
                 for (int n = 0; n < NT; n++)
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
-                        int idx = (16 * m + 4 * g + i) * COUT + 16 * n + r16;
+                        int idx = dw_chan<MT>(m, 4 * g + i) * COUT + dw_chan<NT>(n, r16);
                         if (w == 0)
                             red[idx] = acc[m][n][i];
                         else
