@@ -423,6 +423,7 @@ int conv_backward_weight(const TiledRules &t, const float *X, const float *dY, f
                 break;
             }
         }
+        if (nt == 6 && ct % 2 == 0) mt = 2;  // 96 planes: 2x6 tiles (one dwordx2 + dwordx4/x2 per step) measured 4 % faster than 3x6
         if (!mt) mfma_ok = false;
         if (const char *e = getenv("SEI_DW_MT")) {  // kernel experiments
             int em = atoi(e);
