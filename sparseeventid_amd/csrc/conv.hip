@@ -201,10 +201,12 @@ __global__ __launch_bounds__(256) void conv_dw_mfma_kernel(
     __shared__ int list_sub[DW_LIST_CAP];
     __shared__ int list_tile[DW_LIST_CAP];
     __shared__ int scan_tmp[8];
-    // linear id -> (xcd, k, split group): the K workgroups that walk the same tile range (and re-read the
-    // same dY / X rows) get ids that differ by 8, i.e. run on ONE XCD and share its L2 (speed only)
+    // linear id -> (xcd, ci block, k, split group): the K * (CIN / (16 MT)) workgroups that walk the same tile
+    // range (and re-read the same dY / X rows) get consecutive ids that differ by 8, i.e. run on ONE XCD at about
+    // the same time and share its L2 (speed only)
+    const int CB = CIN / (16 * MT);
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int k = j % K, s = (j / K) * 8 + xcd, cig = blockIdx.z;
+    const int cig = j % CB, k = (j / CB) % K, s = (j / (CB * K)) * 8 + xcd;
     if (s >= S) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r16 = lane & 15, g = lane >> 4;
@@ -377,8 +379,8 @@ static int launch_dw(const TiledRules &t, const float *X, const float *dY, int n
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         attr_set = true;
     }
-    // x = 8 * K * ceil(S/8) linear ids (decoded in the kernel), y = K (carries K only), z = ci blocks
-    dim3 grid(8 * t.K * ((S + 7) / 8), 1, nIn / (16 * MT));
+    // 8 * (ci blocks) * K * ceil(S/8) linear ids, decoded in the kernel
+    dim3 grid(8 * (nIn / (16 * MT)) * t.K * ((S + 7) / 8), 1, 1);
     conv_dw_mfma_kernel<MT, NT><<<grid, 256, lds_bytes, st>>>(X, dY, t.tile_sub_start, t.seg_start, t.sub_src, t.sub_dst,
                                                               t.n_tiles, t.tile_rows, nIn, nOut, tps, S, t.K, slab);
     SEI_LAUNCH_CHECK();
