@@ -135,3 +135,87 @@ def test_wide_layers_on_a_large_level(ci, co):
     assert rel_err(out.features, oo.features) < 1e-4
     assert rel_err(f.grad, fo.grad) < 1e-4
     assert rel_err(conv.weight.grad, W.grad) < 1e-4 and rel_err(conv.bias.grad, b.grad) < 1e-4
+
+
+def test_fused_residual_block_wide_on_a_large_level():
+    """ResidualBlock (sparse_building_blocks.py:61-100) at 128 planes on > 100 000 rows: the fused node seeds
+    conv1's dX kernel with the skip gradient (`sei_conv_backward_input_accumulate`) on the 128-row / column-block
+    plan; output, input gradient and every parameter gradient against the oracle."""
+    import sparseeventid_amd.scn as scn
+    from sparseeventid_amd.config import Encoder
+    from sparseeventid_amd.networks import ResidualBlock
+    from tests.util import random_cloud
+    C, sp, B = 128, [56, 56, 56], 2
+    coords, _ = random_cloud(33, B, sp, 52000, 1)
+    n = len(coords)
+    feats = np.random.default_rng(9).standard_normal((n, C)).astype(np.float32)
+    torch.manual_seed(4)
+    blk = ResidualBlock(nIn=C, nOut=C, dim=3, params=Encoder()).cuda().train()
+    with torch.no_grad():
+        for name, p in blk.named_parameters():
+            if name.endswith("norm.weight"):
+                p.copy_(1 + 0.2 * torch.randn_like(p))
+            elif name.endswith("bias"):
+                p.copy_(0.1 * torch.randn_like(p))
+    f = torch.from_numpy(feats).cuda().requires_grad_(True)
+    t = scn.InputLayer(3, sp)((torch.from_numpy(coords), f, B))
+    out = blk(t)
+    g = torch.randn(out.features.shape, generator=torch.Generator().manual_seed(6))
+    out.features.backward(g.cuda())
+
+    torch.set_num_threads(16)
+    sd = {"b." + k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point and "running" not in k)
+          for k, v in list(blk.named_parameters()) + list(blk.named_buffers())}
+    for k in sd:
+        if "running_mean" in k:
+            sd[k] = torch.zeros_like(sd[k])
+        if "running_var" in k:
+            sd[k] = torch.ones_like(sd[k])
+    fo = torch.from_numpy(feats).requires_grad_(True)
+    ot = scn_cpu.input_layer(coords, fo, B, sp)
+    cfg = scn_cpu.NetConfig()
+    o1 = scn_cpu._block(ot, sd, "b.convolution_1", cfg, [3, 3, 3], True, True)
+    o2 = scn_cpu._block(o1, sd, "b.convolution_2", cfg, [3, 3, 3], False, True)
+    oo = scn_cpu.leaky_relu(scn_cpu.add_table([o2, ot]))
+    oo.features.backward(g)
+    assert rel_err(out.features, oo.features) < 1e-4
+    # Input gradient: a pre-activation that rounds to the other side of a LeakyReLU kink flips that element's
+    # slope (1 vs 1/3) on one side only -- a discrete difference on a handful of the 13 M elements that the
+    # max-norm sees.  So: all but a few elements within 1e-4, and the relative L2 error small.
+    d = (f.grad.detach().cpu().double() - fo.grad.double()).abs()
+    scale = float(fo.grad.abs().max())
+    n_off = int((d > 1e-4 * scale).sum())
+    l2 = float(d.norm() / fo.grad.double().norm())
+    print("input gradient: %d of %d elements off by > 1e-4 (max %.2e), relative L2 %.2e" % (n_off, d.numel(), float(d.max()) / scale, l2))
+    assert n_off < 1e-3 * d.numel() and l2 < 1e-3, (n_off, l2)
+    l2e = lambda a, b_: float((a.detach().cpu().double() - b_.double()).norm() / b_.double().norm().clamp_min(1e-300))
+    gmax = max(float(sd["b." + k].grad.abs().max()) for k, _ in blk.named_parameters())
+    for k, p in blk.named_parameters():
+        og = sd["b." + k].grad
+        if float(og.abs().max()) < 1e-5 * gmax:   # conv bias in front of BatchNorm: analytically zero
+            assert float(p.grad.abs().max()) < 1e-4 * gmax, k
+            continue
+        assert l2e(p.grad, og) < 1e-3, k
+
+    # The sharp check of the accumulate path: the same block through the engine's UNFUSED kernels (conv, BN+act,
+    # conv, BN+add+act as separate autograd nodes; dX = conv-dX, then a separate add of the skip gradient).  The
+    # forward kernels are the same, so the LeakyReLU masks are identical and only summation order differs.
+    fused = {k: p.grad.detach().clone() for k, p in blk.named_parameters()}
+    fused_dx, fused_out = f.grad.detach().clone(), out.features.detach().clone()
+    for p in blk.parameters():
+        p.grad = None
+    f2 = torch.from_numpy(feats).cuda().requires_grad_(True)
+    t2 = scn.InputLayer(3, sp)((torch.from_numpy(coords), f2, B))
+    keep = scn.residual_block_supported
+    scn.residual_block_supported = lambda nplanes: False
+    try:
+        out2 = blk(t2)
+    finally:
+        scn.residual_block_supported = keep
+    out2.features.backward(g.cuda())
+    assert torch.equal(out2.features.detach(), fused_out)
+    assert rel_err(fused_dx, f2.grad) < 1e-5
+    for k, p in blk.named_parameters():
+        if float(p.grad.abs().max()) < 1e-5 * gmax:
+            continue
+        assert rel_err(fused[k], p.grad) < 1e-5, k
