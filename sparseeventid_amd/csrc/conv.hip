@@ -122,7 +122,7 @@ __device__ inline int dw_build_list(const int32_t *__restrict__ tile_sub_start, 
 // rule indices of one sub-chunk, one slot per lane r16 (replicated over the 4 lane groups)
 struct DwItem {
     int src;       // src row of slot r16, -1 = padding / no item
-    int64_t drow;  // global dst row of slot r16
+    int drow;      // global dst row of slot r16 (rows are int32 everywhere in the rulebook)
 };
 
 __device__ __forceinline__ DwItem dw_load_item(const int *list_sub, const int *list_tile, int li, int total, int TR,
@@ -132,7 +132,7 @@ __device__ __forceinline__ DwItem dw_load_item(const int *list_sub, const int *l
     const bool valid = li < total;
     const int lc = valid ? li : 0;
     const int64_t c = valid ? list_sub[lc] : 0;
-    const int64_t rowbase = valid ? (int64_t)list_tile[lc] * TR : 0;
+    const int rowbase = valid ? list_tile[lc] * TR : 0;
     const int sv = sub_src[c * SUB_SLOTS + r16];
     const int dv = sub_dst[c * SUB_SLOTS + r16];
     DwItem it;
@@ -184,10 +184,12 @@ __device__ __forceinline__ DwOps<MT, NT> dw_load_ops(const DwItem &it, int q, in
                                                      int COUT, int ci0) {
     DwOps<MT, NT> o;
     const int src = __shfl(it.src, 4 * q + g);
-    const int64_t drow = __shfl(it.drow, 4 * q + g);
+    const int drow = __shfl(it.drow, 4 * q + g);
     const bool ok = src >= 0;
-    dw_load_vec<MT>(X + (size_t)(ok ? src : 0) * CIN + ci0, r16, ok, o.a);
-    dw_load_vec<NT>(dY + (size_t)(ok ? drow : 0) * COUT, r16, ok, o.b);
+    // row address = base + u32 row * u32 stride: ONE v_mad_u64_u32 per operand (signed 64-bit index math costs four)
+    const uint32_t xr = ok ? (uint32_t)src : 0u, yr = ok ? (uint32_t)drow : 0u;
+    dw_load_vec<MT>(X + ci0 + (uint64_t)xr * (uint32_t)CIN, r16, ok, o.a);
+    dw_load_vec<NT>(dY + (uint64_t)yr * (uint32_t)COUT, r16, ok, o.b);
     o.any = __any(ok);
     return o;
 }
