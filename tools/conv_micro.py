@@ -18,6 +18,8 @@ def main():
     ap.add_argument("--bwd", action="store_true")
     ap.add_argument("--stats", action="store_true")
     ap.add_argument("--kind", default="tracks")
+    ap.add_argument("--order", default="input", choices=["input", "morton", "block8", "shuffle"],
+                    help="row order experiment: re-order each event's voxels before the InputLayer (first-appearance row order)")
     ap.add_argument("--dense", type=int, default=0, help="dense D^3 cube per event instead of the DUNE batch (kernel ceiling: no padding, perfect balance)")
     ap.add_argument("--workers", type=int, default=int(os.environ.get("SEI_GEN_WORKERS", "0")) or min(16, os.cpu_count() or 8))
     a = ap.parse_args()
@@ -35,6 +37,23 @@ def main():
         arr, _ = generate_batch(0, 0, a.events, (900, 900, 900), 50000, a.kind, a.workers)
         from sparseeventid_amd.data import larcvsparse_to_scnsparse_3d
         c, f, b = larcvsparse_to_scnsparse_3d(arr)
+        if a.order != "input":
+            ci = c.astype(np.int64)
+            if a.order == "morton":
+                def spread(v):
+                    v = v & 0x3FF
+                    v = (v | (v << 16)) & 0x030000FF
+                    v = (v | (v << 8)) & 0x0300F00F
+                    v = (v | (v << 4)) & 0x030C30C3
+                    v = (v | (v << 2)) & 0x09249249
+                    return v
+                key = (spread(ci[:, 0]) << 2) | (spread(ci[:, 1]) << 1) | spread(ci[:, 2])
+            elif a.order == "block8":
+                key = (((ci[:, 0] >> 3) * 128 + (ci[:, 1] >> 3)) * 128 + (ci[:, 2] >> 3)) * 512 + ((ci[:, 0] & 7) * 64 + (ci[:, 1] & 7) * 8 + (ci[:, 2] & 7))
+            else:
+                key = np.random.default_rng(0).permutation(len(ci))
+            o = np.lexsort((key, ci[:, 3]))
+            c, f = c[o], f[o]
         t = scn.InputLayer(3, [900, 900, 900])((torch.from_numpy(c), torch.from_numpy(f).cuda(), b))
         t.features = torch.randn(t.features.shape[0], 16, device="cuda")
         for _ in range(a.level):
