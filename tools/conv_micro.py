@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--kind", default="tracks")
     ap.add_argument("--order", default="input", choices=["input", "morton", "block8", "shuffle"],
                     help="row order experiment: re-order each event's voxels before the InputLayer (first-appearance row order)")
+    ap.add_argument("--zeros", action="store_true", help="all-zero features and weights: same instruction stream, minimal switching power (clock probe)")
     ap.add_argument("--dense", type=int, default=0, help="dense D^3 cube per event instead of the DUNE batch (kernel ceiling: no padding, perfect balance)")
     ap.add_argument("--workers", type=int, default=int(os.environ.get("SEI_GEN_WORKERS", "0")) or min(16, os.cpu_count() or 8))
     a = ap.parse_args()
@@ -63,6 +64,9 @@ def main():
     x = torch.randn(n, a.cin, device="cuda", requires_grad=a.bwd)
     t.features = x
     conv = scn.SubmanifoldConvolution(3, a.cin, a.cout, 3, True).cuda()
+    if a.zeros:
+        with torch.no_grad():
+            conv.weight.zero_(); conv.bias.zero_(); x.zero_()
     rb = t.metadata.subm_rulebook(sp, [3, 3, 3])
     out = conv(t)
     torch.cuda.synchronize()
