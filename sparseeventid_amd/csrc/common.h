@@ -68,12 +68,46 @@ __host__ __device__ inline uint64_t mix64(uint64_t k) {
 
 // Locality-preserving slot choice: the 8 keys that differ only in the low 3 bits of x2 (the fastest coordinate)
 // share one 8-slot block = one 64-byte line of `keys`; the block is placed by the hash of the other bits.
-// Collisions step by 8 slots, i.e. to the same position of the next block.  Probes of neighbouring sites along
-// x2 -- what consecutive lanes of the rulebook probe kernel issue -- then hit the same cache line.
+// Probes of neighbouring sites along x2 -- what consecutive lanes of the rulebook probe kernel issue -- then hit
+// the same cache line.  Probe t of a key visits the other 7 slots of its home block first, then walks the following
+// blocks the same way: the sequence covers EVERY slot of the table in `cap` steps (a sequence that only stepped by
+// whole blocks would confine a key to cap/8 slots and spin forever once more than cap/8 keys share x2 mod 8 --
+// planar clouds, spatial size [H,W,1]).  All probe loops are bounded by cap.
 __host__ __device__ inline uint64_t hash_slot0(uint64_t key, uint64_t mask) {
     return ((mix64(key >> 3) << 3) | (key & 7ull)) & mask;
 }
-__host__ __device__ inline uint64_t hash_next(uint64_t s, uint64_t mask) { return (s + 8) & mask; }
+__host__ __device__ inline uint64_t hash_probe(uint64_t s0, uint64_t t, uint64_t mask) {
+    return (((s0 & ~7ull) + ((t >> 3) << 3)) & mask) | ((s0 + t) & 7ull);
+}
+
+#ifdef __HIPCC__
+// Insert key; the slot's value becomes the MIN candidate id that hit it (deterministic representative = first
+// appearance).  Returns the slot, or 0xFFFFFFFF when the table is full (callers raise the device error flag).
+__device__ inline uint32_t hash_insert_min(uint64_t *keys, uint32_t *vals, uint64_t mask, uint64_t key, uint32_t cand) {
+    const uint64_t s0 = hash_slot0(key, mask);
+    for (uint64_t t = 0; t <= mask; t++) {
+        const uint64_t s = hash_probe(s0, t, mask);
+        unsigned long long prev = atomicCAS((unsigned long long *)&keys[s], (unsigned long long)EMPTY_KEY,
+                                            (unsigned long long)key);
+        if (prev == EMPTY_KEY || prev == key) {
+            atomicMin(&vals[s], cand);
+            return (uint32_t)s;
+        }
+    }
+    return 0xFFFFFFFFu;
+}
+__device__ inline int hash_find(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, uint64_t mask,
+                                uint64_t key) {
+    const uint64_t s0 = hash_slot0(key, mask);
+    for (uint64_t t = 0; t <= mask; t++) {
+        const uint64_t s = hash_probe(s0, t, mask);
+        const uint64_t k = keys[s];
+        if (k == key) return (int)vals[s];
+        if (k == EMPTY_KEY) return -1;
+    }
+    return -1;
+}
+#endif
 
 struct HashTable {
     uint64_t *keys = nullptr;

@@ -94,22 +94,7 @@ int exclusive_scan_i32(const int32_t *in, int32_t *out, int64_t n, int32_t *tota
     return 0;
 }
 
-// ------------------------------------------------------------------ hash insert
-// Insert key; the slot's value becomes the MIN candidate id that hit it (deterministic
-// representative = first appearance).  Returns the slot.
-__device__ inline uint32_t hash_insert_min(uint64_t *keys, uint32_t *vals, uint64_t mask, uint64_t key, uint32_t cand) {
-    uint64_t s = hash_slot0(key, mask);
-    for (;;) {
-        unsigned long long prev = atomicCAS((unsigned long long *)&keys[s], (unsigned long long)EMPTY_KEY,
-                                            (unsigned long long)key);
-        if (prev == EMPTY_KEY || prev == key) {
-            atomicMin(&vals[s], cand);
-            return (uint32_t)s;
-        }
-        s = hash_next(s, mask);
-    }
-}
-
+// ------------------------------------------------------------------ hash insert (hash_insert_min: common.h)
 __global__ void input_insert_kernel(const int32_t *__restrict__ coords, int64_t n, int s0, int s1, int s2, int batch,
                                     uint64_t *keys, uint32_t *vals, uint64_t mask, uint32_t *slot_of, int32_t *err) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -120,7 +105,9 @@ __global__ void input_insert_kernel(const int32_t *__restrict__ coords, int64_t 
         slot_of[i] = 0xFFFFFFFFu;
         return;
     }
-    slot_of[i] = hash_insert_min(keys, vals, mask, pack_key(c.x, c.y, c.z, c.w), (uint32_t)i);
+    const uint32_t s = hash_insert_min(keys, vals, mask, pack_key(c.x, c.y, c.z, c.w), (uint32_t)i);
+    if (s == 0xFFFFFFFFu) atomicMin((unsigned int *)err + 2, 0u);  // table full (cannot happen at load <= 0.5)
+    slot_of[i] = s;
 }
 
 __global__ void flag_first_kernel(const uint32_t *slot_of, const uint32_t *vals, int64_t n, int32_t *flag) {
@@ -200,10 +187,10 @@ int build_input_level(sei_metadata *m, const int32_t *coords, int64_t n, const i
     int32_t *flag, *err_total;
     SEI_TRY(pool_alloc_t(&slot_of, n));
     SEI_TRY(pool_alloc_t(&flag, n));
-    SEI_TRY(pool_alloc_t(&err_total, 2));
+    SEI_TRY(pool_alloc_t(&err_total, 4));  // [0] first out-of-range point, [1] row count, [2] table-full flag
     SEI_TRY(pool_alloc_t(&new_vals, lv->ht.mask + 1));
     SEI_TRY(pool_alloc_t(&m->input_row, n));
-    SEI_HIP(hipMemsetAsync(err_total, 0xFF, sizeof(int32_t), st));
+    SEI_HIP(hipMemsetAsync(err_total, 0xFF, 4 * sizeof(int32_t), st));
     SEI_HIP(hipMemsetAsync(new_vals, 0xFF, (lv->ht.mask + 1) * sizeof(uint32_t), st));
     const int T = 256;
     const int nb = (int)((n + T - 1) / T);
@@ -212,13 +199,17 @@ int build_input_level(sei_metadata *m, const int32_t *coords, int64_t n, const i
     flag_first_kernel<<<nb, T, 0, st>>>(slot_of, lv->ht.vals, n, flag);
     SEI_LAUNCH_CHECK();
     SEI_TRY(exclusive_scan_i32(flag, flag, n, err_total + 1, st));
-    int32_t host[2];
-    SEI_HIP(hipMemcpyAsync(host, err_total, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    int32_t host[3];
+    SEI_HIP(hipMemcpyAsync(host, err_total, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     SEI_HIP(hipStreamSynchronize(st));
     if (host[0] != -1) {
         pool_free(slot_of); pool_free(flag); pool_free(err_total); pool_free(new_vals);
         SEI_FAIL("InputLayer: coordinate of input point " + std::to_string((uint32_t)host[0]) +
                  " is outside spatial_size / batch_size");
+    }
+    if (host[2] != -1) {
+        pool_free(slot_of); pool_free(flag); pool_free(err_total); pool_free(new_vals);
+        SEI_FAIL("InputLayer: hash table full");
     }
     int64_t nr = host[1];
     lv->n = nr;

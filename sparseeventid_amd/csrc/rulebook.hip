@@ -6,17 +6,6 @@
 
 namespace sei {
 
-__device__ inline int hash_find(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, uint64_t mask,
-                                uint64_t key) {
-    uint64_t s = hash_slot0(key, mask);
-    for (;;) {
-        uint64_t k = keys[s];
-        if (k == key) return (int)vals[s];
-        if (k == EMPTY_KEY) return -1;
-        s = hash_next(s, mask);
-    }
-}
-
 // One thread per (tile, k, row-in-tile): nbr[(tile*K + k)*TR + r] = src row feeding dst row
 // tile*TR + r through offset k, or -1.  Consecutive lanes = consecutive dst rows, same offset:
 // coalesced coord reads / nbr writes, and the probed keys are spatial neighbours of each other.
@@ -216,22 +205,9 @@ __device__ inline bool candidate(int4 p, int j, const ProbeGeom &g, int o0, int 
     return *q0 <= h0 && *q1 <= h1 && *q2 <= h2;
 }
 
-__device__ inline uint32_t hash_insert_min_dev(uint64_t *keys, uint32_t *vals, uint64_t mask, uint64_t key, uint32_t cand) {
-    uint64_t s = hash_slot0(key, mask);
-    for (;;) {
-        unsigned long long prev = atomicCAS((unsigned long long *)&keys[s], (unsigned long long)EMPTY_KEY,
-                                            (unsigned long long)key);
-        if (prev == EMPTY_KEY || prev == key) {
-            atomicMin(&vals[s], cand);
-            return (uint32_t)s;
-        }
-        s = hash_next(s, mask);
-    }
-}
-
 __global__ void out_insert_kernel(const int32_t *__restrict__ in_coords, int64_t n, int mult, int m1, int m2,
                                   ProbeGeom g, int o0, int o1, int o2, uint64_t *keys, uint32_t *vals, uint64_t mask,
-                                  uint32_t *slot_of) {
+                                  uint32_t *slot_of, int32_t *err) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n * mult) return;
     int64_t i = t / mult;
@@ -242,7 +218,9 @@ __global__ void out_insert_kernel(const int32_t *__restrict__ in_coords, int64_t
         slot_of[t] = 0xFFFFFFFFu;
         return;
     }
-    slot_of[t] = hash_insert_min_dev(keys, vals, mask, pack_key(q0, q1, q2, p.w), (uint32_t)t);
+    const uint32_t s = hash_insert_min(keys, vals, mask, pack_key(q0, q1, q2, p.w), (uint32_t)t);
+    if (s == 0xFFFFFFFFu) *err = 1;  // table full (cannot happen at load <= 0.5)
+    slot_of[t] = s;
 }
 
 __global__ void out_flag_kernel(const uint32_t *slot_of, const uint32_t *vals, int64_t n, int32_t *flag) {
@@ -306,18 +284,21 @@ int build_strided_level(sei_metadata *m, Level *lin, const int32_t size[3], cons
         int32_t *flag, *total;
         SEI_TRY(pool_alloc_t(&slot_of, cand));
         SEI_TRY(pool_alloc_t(&flag, cand));
-        SEI_TRY(pool_alloc_t(&total, 2));
+        SEI_TRY(pool_alloc_t(&total, 2));  // [0] number of output sites, [1] table-full flag
+        SEI_HIP(hipMemsetAsync(total, 0, 2 * sizeof(int32_t), st));
         SEI_TRY(pool_alloc_t(&new_vals, lo->ht.mask + 1));
         SEI_HIP(hipMemsetAsync(new_vals, 0xFF, (lo->ht.mask + 1) * sizeof(uint32_t), st));
         unsigned nb = (unsigned)((cand + 255) / 256);
         out_insert_kernel<<<nb, 256, 0, st>>>(lin->coords, n, mult, m1, m2, g, osz[0], osz[1], osz[2], lo->ht.keys,
-                                              lo->ht.vals, lo->ht.mask, slot_of);
+                                              lo->ht.vals, lo->ht.mask, slot_of, total + 1);
         out_flag_kernel<<<nb, 256, 0, st>>>(slot_of, lo->ht.vals, cand, flag);
         SEI_LAUNCH_CHECK();
         SEI_TRY(exclusive_scan_i32(flag, flag, cand, total, st));
-        int32_t host;
-        SEI_HIP(hipMemcpyAsync(&host, total, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        int32_t host2[2];
+        SEI_HIP(hipMemcpyAsync(host2, total, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
         SEI_HIP(hipStreamSynchronize(st));
+        if (host2[1]) SEI_FAIL("Convolution: hash table full");
+        const int32_t host = host2[0];
         lo->n = host;
         SEI_TRY(pool_alloc_t(&lo->coords, 4 * (int64_t)(host > 0 ? host : 1)));
         out_assign_kernel<<<nb, 256, 0, st>>>(lin->coords, n, mult, m1, m2, g, osz[0], osz[1], osz[2], slot_of,

@@ -219,3 +219,33 @@ def test_fused_residual_block_wide_on_a_large_level():
         if float(p.grad.abs().max()) < 1e-5 * gmax:
             continue
         assert rel_err(fused[k], p.grad) < 1e-5, k
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Hash-table probe coverage (round-1 advisor finding): keys that share x2 mod 8 used to be confined to cap/8 slots
+# and the probe loops spun forever once a class filled up.  Planar clouds and thin last dimensions are ordinary
+# InputLayer / Convolution inputs (2-D data is [planes, H, W]).
+@pytest.mark.parametrize("sp,n", [([64, 64, 8], 400), ([96, 80, 1], 3000), ([40, 40, 3], 2500)])
+def test_hash_probe_covers_table_same_x2_class(sp, n):
+    import sparseeventid_amd.scn as scn
+    rng = np.random.default_rng(1)
+    vol = sp[0] * sp[1]
+    flat = rng.choice(vol, size=n, replace=False)
+    x2 = np.full(n, 5 % sp[2]) if sp[2] > 3 else rng.integers(0, sp[2], n)   # one x2 class / thin last dimension
+    coords = np.stack([flat // sp[1], flat % sp[1], x2, np.zeros(n, np.int64)], -1).astype(np.float64)
+    coords = np.unique(coords, axis=0)
+    rng.shuffle(coords)
+    feats = rng.standard_normal((len(coords), 1)).astype(np.float32)
+    t = scn.InputLayer(3, sp)((torch.from_numpy(coords), torch.from_numpy(feats).cuda(), 1))
+    o = scn_cpu.input_layer(coords, torch.from_numpy(feats), 1, sp)
+    assert np.array_equal(t.get_spatial_locations().numpy(), o.coords.astype(np.int64))
+    # neighbour probes (hits and misses) and strided-site insertion on the same table shapes
+    filt = [3, 3, 1] if sp[2] == 1 else [3, 3, 3]
+    rb = t.metadata.subm_rulebook(sp, filt)
+    ostart, ori, oro = scn_cpu.subm_rules(o.coords, sp, filt)
+    assert rb.n_rules == len(ori)
+    size = [2, 2, 1] if sp[2] < 4 else [2, 2, 2]
+    rbc = t.metadata.conv_rulebook(sp, size, size)
+    oc, osp, _, _, _ = scn_cpu.conv_rules(o.coords, sp, size, size)
+    assert np.array_equal(t.metadata.coords(osp, "cuda").cpu().numpy(), oc)
+    assert rbc.spatial_out == osp
