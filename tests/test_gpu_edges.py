@@ -229,11 +229,13 @@ def test_fused_residual_block_wide_on_a_large_level():
 def test_hash_probe_covers_table_same_x2_class(sp, n):
     import sparseeventid_amd.scn as scn
     rng = np.random.default_rng(1)
-    vol = sp[0] * sp[1]
-    flat = rng.choice(vol, size=n, replace=False)
-    x2 = np.full(n, 5 % sp[2]) if sp[2] > 3 else rng.integers(0, sp[2], n)   # one x2 class / thin last dimension
+    if sp[2] > 3:   # every point in ONE x2 class
+        flat = rng.choice(sp[0] * sp[1], size=n, replace=False)
+        x2 = np.full(n, 5)
+    else:           # thin last dimension: only sp[2] of the 8 classes exist
+        flat3 = rng.choice(sp[0] * sp[1] * sp[2], size=n, replace=False)
+        flat, x2 = flat3 // sp[2], flat3 % sp[2]
     coords = np.stack([flat // sp[1], flat % sp[1], x2, np.zeros(n, np.int64)], -1).astype(np.float64)
-    coords = np.unique(coords, axis=0)
     rng.shuffle(coords)
     feats = rng.standard_normal((len(coords), 1)).astype(np.float32)
     t = scn.InputLayer(3, sp)((torch.from_numpy(coords), torch.from_numpy(feats).cuda(), 1))
