@@ -312,22 +312,49 @@ static double conv_bytes(const TiledRules &t, int nIn, int nOut) {
     return 4.0 * t.n_src * nIn + 4.0 * t.n_dst * nOut + 8.0 * t.n_rules + 4.0 * t.K * nIn * nOut;
 }
 
+static int rulebook_K(const sei_rulebook_t *rb) { return rb->size[0] * rb->size[1] * rb->size[2]; }
+
+// The MFMA kernels read weights / biases with 16-byte loads.  torch allocations and the parameter arena
+// (distributed.py) are aligned; a caller's odd view is staged through an aligned pool block instead of faulting.
+struct AlignedArg {
+    const float *p = nullptr;
+    float *tmp = nullptr;
+    int stage(const float *src, size_t count, hipStream_t st) {
+        p = src;
+        if (!src || ((uintptr_t)src & 15) == 0) return 0;
+        SEI_TRY(pool_alloc_t(&tmp, count));
+        SEI_HIP(hipMemcpyAsync(tmp, src, count * sizeof(float), hipMemcpyDeviceToDevice, st));
+        p = tmp;
+        return 0;
+    }
+    ~AlignedArg() { pool_free(tmp); }
+};
+
 int sei_conv_forward(sei_rulebook_t *rb, const float *X, const float *W, const float *bias, float *Y, int32_t nIn,
                      int32_t nOut, sei_stream_t stream) {
     if (!rb) SEI_FAIL("null rulebook");
     hipStream_t st = (hipStream_t)stream;
     const TiledRules *t;
     const int64_t n_dst = rb->lout ? rb->lout->n : 0;
-    SEI_TRY(get_tiled(rb, false, conv_tile_rows(nIn, nOut, n_dst), &t, st));
-    const int cgp = conv_col_group(nIn, nOut, n_dst);
-    if (cgp == 0) {
+    const ConvPlan p = plan_conv(nIn, nOut, rulebook_K(rb), n_dst);
+    SEI_TRY(get_tiled(rb, false, p.tile_rows, &t, st));
+    AlignedArg ab, aw;
+    if (p.kind != 0) {
+        SEI_TRY(ab.stage(bias, nOut, st));
+        bias = ab.p;
+    }
+    if (p.kind != 1) {  // natural weight layout: no copy
+        if (p.kind == 2) {
+            SEI_TRY(aw.stage(W, (size_t)t->K * nIn * nOut, st));
+            W = aw.p;
+        }
         ProfScope ps(PROF_CONV_FWD, st, 2.0 * t->n_rules * nIn * nOut, conv_bytes(*t, nIn, nOut));
         return conv_forward(*t, X, W, bias, Y, nIn, nOut, st);
     }
-    // the MFMA kernel reads B operands with wide LDS loads from column-permuted weights (tiny copy, <= 4 MB)
+    // the workgroup-tile MFMA kernel reads B operands with wide LDS loads from column-permuted weights (tiny copy, <= 4 MB)
     float *Wp;
     SEI_TRY(pool_alloc_t(&Wp, (size_t)t->K * nIn * nOut));
-    int rc = conv_transform_weights(W, Wp, t->K, nIn, nOut, false, false, cgp, conv_col_blocks(nIn, nOut, n_dst), st);
+    int rc = conv_transform_weights(W, Wp, t->K, nIn, nOut, false, false, p.col_group, p.blocks, st);
     if (!rc) {
         ProfScope ps(PROF_CONV_FWD, st, 2.0 * t->n_rules * nIn * nOut, conv_bytes(*t, nIn, nOut));
         rc = conv_forward(*t, X, Wp, bias, Y, nIn, nOut, st);
@@ -343,14 +370,15 @@ static int conv_backward_input_impl(sei_rulebook_t *rb, const float *dY, const f
     const TiledRules *t;
     // roles swap: contraction over nOut, result has nIn columns
     const int64_t n_dst = rb->lin ? rb->lin->n : 0;
-    SEI_TRY(get_tiled(rb, true, conv_tile_rows(nOut, nIn, n_dst), &t, st));
-    if (dX_init && (!conv_supports_init(nOut, nIn) || t->n_sub == 0))
+    const ConvPlan p = plan_conv(nOut, nIn, rulebook_K(rb), n_dst);
+    SEI_TRY(get_tiled(rb, true, p.tile_rows, &t, st));
+    if (dX_init && (p.kind == 0 || t->n_sub == 0))
         SEI_FAIL("conv_backward_input_accumulate: not supported for these plane counts");
     float *Wt;
     SEI_TRY(pool_alloc_t(&Wt, (size_t)t->K * nIn * nOut));
-    // Wt[k'][co][ci] = W[K-1-k' (submanifold mirror) or k'][ci][co], columns (ci) permuted for the kernel
-    int rc = conv_transform_weights(W, Wt, t->K, nIn, nOut, true, rb->submanifold, conv_col_group(nOut, nIn, n_dst),
-                                    conv_col_blocks(nOut, nIn, n_dst), st);
+    // Wt[k'][co][ci] = W[K-1-k' (submanifold mirror) or k'][ci][co] (kind 1: columns (ci) permuted for the kernel)
+    int rc = conv_transform_weights(W, Wt, t->K, nIn, nOut, true, rb->submanifold, p.kind == 1 ? p.col_group : 0,
+                                    p.kind == 1 ? p.blocks : 1, st);
     if (!rc) {
         ProfScope ps(PROF_CONV_BWD_IN, st, 2.0 * t->n_rules * nIn * nOut, conv_bytes(*t, nOut, nIn));
         rc = conv_forward(*t, dY, Wt, nullptr, dX, nOut, nIn, st, dX_init);

@@ -199,13 +199,24 @@ int get_any_tiled(sei_rulebook *rb, bool transposed, const TiledRules **out, hip
 int build_strided_level(sei_metadata *m, Level *lin, const int32_t size[3], const int32_t stride[3], sei_rulebook *rb,
                         hipStream_t st);
 int export_rules(const TiledRules &t, int64_t *start_host, int32_t *rin, int32_t *rout, hipStream_t st);
-// conv.hip
-int conv_tile_rows(int nIn, int nOut, int64_t n_dst);  // tile size the forward kernel wants for these plane / row counts
+// conv_fwd.hip / conv_wave.hip
+// How one convolution (forward, or dX with the plane counts swapped) runs: decided ONCE per call from the plane
+// counts, the filter volume of the rulebook and the dst row count, and threaded through rulebook build, weight
+// transform and launch.
+struct ConvPlan {
+    int kind = 0;        // 0 scalar tile kernels (tiny / odd plane counts), 1 workgroup-tile MFMA kernel, 2 wave-private MFMA kernel
+    int tile_rows = 0;   // rulebook variant (dst rows per tile)
+    int col_group = 0;   // kind 1: width of the column groups whose columns are stored permuted (0 = natural layout)
+    int blocks = 1;      // column blocks (kind 1: weights stored as [block][K][nIn][nOut/blocks])
+    int nt = 0, cs = 0, slj = 0, maxs = 0, g = 0;
+    size_t lds_bytes = 0;
+};
+ConvPlan plan_conv(int nIn, int nOut, int K, int64_t n_dst);
+bool plan_wave(int nIn, int nOut, int K, int64_t n_dst, ConvPlan *p);
 int conv_forward(const TiledRules &t, const float *X, const float *W, const float *bias, float *Y, int nIn, int nOut,
                  hipStream_t st, const float *init = nullptr);
-bool conv_supports_init(int nIn, int nOut);
-int conv_col_group(int nIn, int nOut, int64_t n_dst);
-int conv_col_blocks(int nIn, int nOut, int64_t n_dst);  // > 1: weights stored as [block][K][nIn][nOut/blocks] (one workgroup per column block)
+int conv_forward_wave(const TiledRules &t, const ConvPlan &p, const float *X, const float *W, const float *bias, float *Y,
+                      int nIn, int nOut, const float *init, hipStream_t st);
 // Wout[k][r][perm(c)]: transpose=false: rows=nIn, cols=nOut (forward); transpose=true: Wout[k][co][perm(ci)] = W[ks][ci][co]
 // with ks = flip ? K-1-k : k (dX).  perm = column permutation inside groups of `col_group` columns (0 = identity).
 int conv_transform_weights(const float *W, float *Wout, int K, int nIn, int nOut, bool transpose, bool flip, int col_group, int blocks,

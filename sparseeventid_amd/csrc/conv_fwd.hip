@@ -446,12 +446,6 @@ __global__ void fill_bias_kernel(float *Y, int64_t n, int C, const float *bias) 
     if (t < n * C) Y[t] = bias ? bias[t % C] : 0.f;
 }
 
-struct FwdPlan {
-    bool mfma;
-    int nt, cs, slj, maxs, tile_rows, blocks;
-    size_t lds_bytes;
-};
-
 static size_t fwd_lds(int tile_rows, int nOut, int slj, int K) {
     return ((size_t)tile_rows * (nOut + APAD) + 2 * 16 * slj * nOut) * sizeof(float) + (K + 1) * sizeof(int);
 }
@@ -474,10 +468,10 @@ static bool env_plan(int nOut, int *maxs, int *cs, int *slj, int *blocks) {
     return false;
 }
 
-static FwdPlan plan_forward(int nIn, int nOut, int K, int64_t n_dst) {
-    FwdPlan p{};
-    p.mfma = (nIn % 16 == 0) && (nOut % 16 == 0) && nIn >= 16 && nOut <= 256;
-    if (p.mfma) {
+static ConvPlan plan_tile(int nIn, int nOut, int K, int64_t n_dst) {
+    ConvPlan p{};
+    bool mfma = (nIn % 16 == 0) && (nOut % 16 == 0) && nIn >= 16 && nOut <= 256;
+    if (mfma) {
         // The tiling depends on nOut (and, for the tile height of wide layers, on the row count).
         // nOut <= 96: 128-row tiles, one workgroup owns all columns.  Wider: one workgroup per (tile, column
         // block) of <= 4 column tiles -- the LDS tile and the weight slices shrink with the block, so 128-row
@@ -509,32 +503,27 @@ static FwdPlan plan_forward(int nIn, int nOut, int K, int64_t n_dst) {
         p.nt = tiles / p.cs / p.blocks;
         p.tile_rows = 16 * p.maxs * (4 / p.cs);
         p.lds_bytes = fwd_lds(p.tile_rows, nOut / p.blocks, p.slj, K);
-        if (p.lds_bytes > 160 * 1024) p.mfma = false;
+        if (p.lds_bytes > 160 * 1024) mfma = false;
     }
-    if (!p.mfma) {
+    p.kind = mfma ? 1 : 0;
+    p.col_group = mfma ? p.nt * 16 : 0;
+    if (!mfma) {
+        p.blocks = 1;
         p.tile_rows = (size_t)256 * nOut * sizeof(float) <= 96 * 1024 ? 256 : 128;
         p.lds_bytes = (size_t)p.tile_rows * nOut * sizeof(float);
     }
     return p;
 }
 
-int conv_tile_rows(int nIn, int nOut, int64_t n_dst) { return plan_forward(nIn, nOut, 27, n_dst).tile_rows; }
-
-// column-group width (floats) whose columns the forward kernel expects permuted; 0 = generic kernel, no permutation
-bool conv_supports_init(int nIn, int nOut) { return plan_forward(nIn, nOut, 27, 0).mfma; }
-
-int conv_col_blocks(int nIn, int nOut, int64_t n_dst) {
-    FwdPlan p = plan_forward(nIn, nOut, 27, n_dst);
-    return p.mfma ? p.blocks : 1;
-}
-
-int conv_col_group(int nIn, int nOut, int64_t n_dst) {
-    FwdPlan p = plan_forward(nIn, nOut, 27, n_dst);
-    return p.mfma ? p.nt * 16 : 0;
+// the plan of one convolution call (forward, or dX with the plane counts swapped)
+ConvPlan plan_conv(int nIn, int nOut, int K, int64_t n_dst) {
+    ConvPlan p{};
+    if (plan_wave(nIn, nOut, K, n_dst, &p)) return p;
+    return plan_tile(nIn, nOut, K, n_dst);
 }
 
 template <int NT, int CS, int SLJ, int MAXS>
-static int launch_mfma(const TiledRules &t, const FwdPlan &p, const float *X, const float *W, const float *bias,
+static int launch_mfma(const TiledRules &t, const ConvPlan &p, const float *X, const float *W, const float *bias,
                        float *Y, int nIn, const float *init, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -564,10 +553,11 @@ int conv_forward(const TiledRules &t, const float *X, const float *W, const floa
         SEI_LAUNCH_CHECK();
         return 0;
     }
-    FwdPlan p = plan_forward(nIn, nOut, t.K, t.n_dst);
-    if (init && (!p.mfma || t.n_sub == 0)) SEI_FAIL("conv_forward: init is only supported by the MFMA kernel");
+    ConvPlan p = plan_conv(nIn, nOut, t.K, t.n_dst);
+    if (init && (p.kind == 0 || t.n_sub == 0)) SEI_FAIL("conv_forward: init is only supported by the MFMA kernels");
     if (p.tile_rows != t.tile_rows) SEI_FAIL("conv_forward: rulebook tile size does not match the kernel plan");
-    if (p.mfma) {
+    if (p.kind == 2) return conv_forward_wave(t, p, X, W, bias, Y, nIn, nOut, init, st);
+    if (p.kind == 1) {
         // default plans
         FWD_BOTH_SLJ(1, 1, 2) FWD_BOTH_SLJ(2, 1, 2) FWD_BOTH_SLJ(3, 1, 2) FWD_BOTH_SLJ(4, 1, 2) FWD_BOTH_SLJ(5, 1, 2)
         FWD_BOTH_SLJ(6, 1, 2)

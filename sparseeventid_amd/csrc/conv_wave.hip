@@ -1,0 +1,373 @@
+// Sparse convolution forward / dX for gfx950, wave-private form (scn.SubmanifoldConvolution / scn.Convolution:
+// resnet.py:30-50,105-110; sparse_building_blocks.py:29-34,110-117).
+//
+// One WAVEFRONT owns a tile of TR (64/128) dst rows x NC = 16*NT output columns whose fp32 accumulators live in
+// its private LDS; there is no barrier, no shared weight buffer and no inter-wave dependency anywhere in the
+// kernel.  The wave walks the filter offsets k; the tile's rules of one k are compacted into sub-chunks of 16
+// rules (the same tiled rulebook the workgroup-tile kernel uses, built with tile_rows = TR) and processed in
+// groups of up to G sub-chunks that share the B operands:
+//   * A (features): src rows gathered straight into MFMA A-operand registers, float4 per lane per 16 input planes,
+//     one slice ahead of the MFMAs that consume them;
+//   * B (weights): read from W in its NATURAL [K][nIn][nOut] layout straight from L2 (W is <= 4 MB and shared by
+//     every wave on the chip), one slice ahead; MFMA column tile (4q+j, lane r) is output column 64q + 4r + j, so
+//     one global_load_dwordx4 feeds four column tiles -- no weight permutation pass for the forward;
+//   * v_mfma_f32_16x16x4_f32 (exact fp32) into zero-initialised accumulators, one chain of nIn/4 steps per offset;
+//   * after the offset's last slice the 16 x NC partial sums are added to the tile rows they target by a plain LDS
+//     read-modify-write; with the column map above a lane's values of four column tiles are 16 contiguous bytes:
+//     ds_read_b128 / ds_write_b128 instead of four b32 pairs.
+// Rows of one offset are distinct and a wave's LDS operations complete in order, so the summation order is fixed
+// (and the same as the reference's per-offset  out[rows] += in[rows] @ W[k]): run-to-run deterministic, no
+// atomics; every dst row is written to HBM exactly once.  Compared with the workgroup-tile kernel the structural
+// efficiency on the DUNE batch rises from padding x wave balance = 0.24 / 0.55 / 0.66 / 0.69 (levels 0-3) to the
+// padding of 64-row tiles alone, 0.46 / 0.73 / 0.82 / 0.84 (tools/structure_stats.py): waves never wait for each
+// other, and the per-phase barrier, zero-init and weight-staging costs are gone.
+#include "common.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+namespace sei {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 wmfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// Unconditional load of a clamped row, and NO select: a padding slot (src < 0) reads row 0 and its products are
+// garbage, but an MFMA output row depends on its own A row only and padding slots are never written back (wrmw).
+// (A select on the loaded value would make hipcc wait for the gather right where it is issued.)
+__device__ __forceinline__ float4 wload_a(const float *__restrict__ X, int src, int CIN, int off) {
+    const uint32_t row = (uint32_t)(src > 0 ? src : 0);
+    return *reinterpret_cast<const float4 *>(X + (uint64_t)row * (uint32_t)CIN + off);
+}
+
+// B operands of one input plane for the NT column tiles: column tile 4q+j at lane r16 is column 64q + 4*r16 + j
+// (remainder tiles: pairs at 2*r16 + j, a single tile at r16) of the wave's column block -- wide loads from W's
+// natural row-major layout.
+template <int NT>
+__device__ __forceinline__ void wload_b(const float *__restrict__ wrow, int r16, float (&b)[NT]) {
+    constexpr int B4 = NT / 4, REM = NT % 4;
+#pragma unroll
+    for (int q = 0; q < B4; q++) {
+        const float4 v = *reinterpret_cast<const float4 *>(wrow + 64 * q + 4 * r16);
+        b[4 * q + 0] = v.x; b[4 * q + 1] = v.y; b[4 * q + 2] = v.z; b[4 * q + 3] = v.w;
+    }
+    if (REM >= 2) {
+        const float2 v = *reinterpret_cast<const float2 *>(wrow + 64 * B4 + 2 * r16);
+        b[4 * B4 + 0] = v.x; b[4 * B4 + 1] = v.y;
+    }
+    if (REM == 1) b[4 * B4] = wrow[64 * B4 + r16];
+    if (REM == 3) b[4 * B4 + 2] = wrow[64 * B4 + 32 + r16];
+}
+
+// tile[dst rows of the sub-chunk] += partial sums.  D[row = 4g+i][col tile n] of lane (g, r16) belongs to rule slot
+// 4g+i; slots [0, nv) are rules (padding sits at the end of a sub-chunk and must not write: its dst is row 0).
+// All reads are issued before the adds.
+template <int NT>
+__device__ __forceinline__ void wrmw(float *acc_tile, int AS, uint32_t d4, int nv, int g, int r16,
+                                     const f32x4 (&acc)[NT]) {
+    constexpr int B4 = NT / 4, REM = NT % 4;
+    float4 t4[4][B4 > 0 ? B4 : 1];
+    float2 t2[4];
+    float t1[4];
+    float *base[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        base[i] = acc_tile + ((d4 >> (8 * i)) & 0xFF) * AS;
+#pragma unroll
+        for (int q = 0; q < B4; q++) t4[i][q] = *reinterpret_cast<const float4 *>(base[i] + 64 * q + 4 * r16);
+        if (REM >= 2) t2[i] = *reinterpret_cast<const float2 *>(base[i] + 64 * B4 + 2 * r16);
+        if (REM == 1) t1[i] = base[i][64 * B4 + r16];
+        if (REM == 3) t1[i] = base[i][64 * B4 + 32 + r16];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        if (4 * g + i < nv) {
+#pragma unroll
+            for (int q = 0; q < B4; q++) {
+                float4 v = t4[i][q];
+                v.x += acc[4 * q + 0][i]; v.y += acc[4 * q + 1][i]; v.z += acc[4 * q + 2][i]; v.w += acc[4 * q + 3][i];
+                *reinterpret_cast<float4 *>(base[i] + 64 * q + 4 * r16) = v;
+            }
+            if (REM >= 2) {
+                float2 v = t2[i];
+                v.x += acc[4 * B4 + 0][i]; v.y += acc[4 * B4 + 1][i];
+                *reinterpret_cast<float2 *>(base[i] + 64 * B4 + 2 * r16) = v;
+            }
+            if (REM == 1) base[i][64 * B4 + r16] = t1[i] + acc[4 * B4][i];
+            if (REM == 3) base[i][64 * B4 + 32 + r16] = t1[i] + acc[4 * B4 + 2][i];
+        }
+    }
+}
+
+template <int G>
+struct WaveIdx {
+    int src[G];       // lane r16: src row of rule slot r16 of sub-chunk m (raw load; validity applied by row())
+    uint32_t d4[G];   // lane group g: packed tile-local dst rows of slots 4g..4g+3
+    int cnt;          // sub-chunks of the group (wave-uniform, 0 past the end)
+    __device__ __forceinline__ int row(int m) const { return m < cnt ? src[m] : -1; }
+};
+
+// one slice (16 input planes = 4 MFMA steps) for MS sub-chunks sharing the B operands
+template <int NT, int G, int MS>
+__device__ __forceinline__ void wslice(const float4 (&a)[G], const float (&b)[4][NT], f32x4 (&acc)[MS][NT]) {
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+#pragma unroll
+        for (int m = 0; m < MS; m++) {
+            const float av = e == 0 ? a[m].x : e == 1 ? a[m].y : e == 2 ? a[m].z : a[m].w;
+#pragma unroll
+            for (int n = 0; n < NT; n++) acc[m][n] = wmfma16(av, b[e][n], acc[m][n]);
+        }
+    }
+}
+
+// operands of slice j (input planes 16j .. 16j+15) of offset k for the G sub-chunks with src rows `rows`
+template <int NT, int G>
+__device__ __forceinline__ void wprefetch(const float *__restrict__ X, const float *__restrict__ wl, int ldy, int CIN,
+                                          int k, int j, const int (&rows)[G], int g, int r16, float4 (&a)[G],
+                                          float (&b)[4][NT]) {
+#pragma unroll
+    for (int m = 0; m < G; m++) a[m] = wload_a(X, rows[m], CIN, 16 * j + 4 * g);
+    const float *wn = wl + ((size_t)k * CIN + 16 * j) * ldy;
+#pragma unroll
+    for (int e = 0; e < 4; e++) wload_b<NT>(wn + (size_t)e * ldy, r16, b[e]);
+}
+
+// One group = MS sub-chunks of offset kc: all NS slices, then the read-modify-write of the tile rows.  On entry
+// (a0, b0) hold slice 0 of this group; on exit they hold slice 0 of the NEXT group (rows rn, offset kn).  The slices
+// ping-pong between two operand sets so that no register copies sit between the MFMAs, and every slice's loads are
+// issued one slice (>= 4*MS*NT MFMAs) before they are consumed.  Straight-line per MS: the group size is dispatched
+// ONCE outside (a branch inside the slice loop made hipcc copy all accumulators every slice).
+template <int NT, int G, int MS>
+__device__ __forceinline__ void wgroup(const float *__restrict__ X, const float *__restrict__ wl, int ldy, int CIN, int NS,
+                                       int kc, int kn, const int (&rc)[G], const int (&rn)[G], const uint32_t (&d4)[G],
+                                       const int (&src)[G], float *acc_tile, int g, int r16, float4 (&a0)[G],
+                                       float (&b0)[4][NT]) {
+    constexpr int NC = 16 * NT;
+    float4 a1[G];
+    float b1[4][NT];
+    f32x4 acc[MS][NT];
+#pragma unroll
+    for (int m = 0; m < MS; m++)
+#pragma unroll
+        for (int n = 0; n < NT; n++) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int j = 0;
+    for (; j + 2 <= NS; j += 2) {
+        wprefetch<NT, G>(X, wl, ldy, CIN, kc, j + 1, rc, g, r16, a1, b1);
+        // the loads above are ISSUED before this slice's MFMAs (hipcc otherwise sinks them behind the MFMAs)
+        __builtin_amdgcn_sched_barrier(0);
+        wslice<NT, G, MS>(a0, b0, acc);
+        const bool same = j + 2 < NS;  // else: slice 0 of the next group
+        int rr[G];
+#pragma unroll
+        for (int m = 0; m < G; m++) rr[m] = same ? rc[m] : rn[m];
+        wprefetch<NT, G>(X, wl, ldy, CIN, same ? kc : kn, same ? j + 2 : 0, rr, g, r16, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        wslice<NT, G, MS>(a1, b1, acc);
+    }
+    if (j < NS) {  // odd slice count: the next group's slice 0 lands in the second set and is moved over
+        wprefetch<NT, G>(X, wl, ldy, CIN, kn, 0, rn, g, r16, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        wslice<NT, G, MS>(a0, b0, acc);
+#pragma unroll
+        for (int m = 0; m < G; m++) a0[m] = a1[m];
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+#pragma unroll
+            for (int n = 0; n < NT; n++) b0[e][n] = b1[e][n];
+    }
+#pragma unroll
+    for (int m = 0; m < MS; m++) {
+        const int nv = __popcll(__ballot(src[m] >= 0) & 0xFFFFull);
+        wrmw<NT>(acc_tile, NC, d4[m], nv, g, r16, acc[m]);
+    }
+}
+
+constexpr int wave_occ(int nt, int g) {
+    // waves per SIMD the register allocator should aim for: accumulators + RMW temporaries + two A and two B
+    // slice sets + ~48 registers of addressing / indices (the LDS tile decides the real occupancy)
+    const int est = g * nt * 4 + nt * 4 + 2 * g * 4 + 2 * 4 * nt + 48;
+    return est <= 120 ? 4 : (est <= 160 ? 3 : (est <= 248 ? 2 : 1));
+}
+
+template <int NT, int G>
+__global__ __launch_bounds__(64, wave_occ(NT, G)) void conv_wave_mfma_kernel(
+    const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ Y,
+    const int32_t *__restrict__ tile_sub_start, const int32_t *__restrict__ tile_seg,
+    const int32_t *__restrict__ sub_src, const uint8_t *__restrict__ sub_dst, int64_t n_dst, int K, int CIN, int n_tiles,
+    const float *__restrict__ init, int ldy, int blocks, int TR) {
+    extern __shared__ float lds[];
+    constexpr int NC = 16 * NT;  // columns of this wave = LDS row stride
+    // workgroups (= waves) are dealt round-robin to the 8 XCDs: give every XCD one contiguous run of tiles so that
+    // neighbouring tiles (which gather many of the same src rows) share that XCD's L2; the column blocks of a tile
+    // are neighbours in this order (speed only)
+    const int nwork = n_tiles * blocks;
+    const int per_xcd = (nwork + 7) >> 3;
+    const int vid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (vid >= nwork) return;
+    const int tile = vid / blocks, cblk = vid - tile * blocks;
+    const int col0 = cblk * NC;
+    const int lane = threadIdx.x, r16 = lane & 15, g = lane >> 4;
+    float *acc_tile = lds;
+
+    // accumulators start from the bias, or from the rows of `init` (Y = init + conv: gradient accumulation)
+    {
+        constexpr int V = NC >> 2;
+        const int64_t row0i = (int64_t)tile * TR;
+        for (int idx = lane; idx < TR * V; idx += 64) {
+            const int r = idx / V, v = idx - r * V;
+            float4 b = bias ? *reinterpret_cast<const float4 *>(bias + col0 + 4 * v) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (init && row0i + r < n_dst)
+                b = *reinterpret_cast<const float4 *>(init + (size_t)(row0i + r) * ldy + col0 + 4 * v);
+            *reinterpret_cast<float4 *>(acc_tile + (size_t)r * NC + 4 * v) = b;
+        }
+    }
+
+    // segment table of the tile: lane l holds seg[l] (K + 1 <= 64); nonempty offsets as a bit mask
+    const int segv = lane <= K ? tile_seg[(size_t)tile * (K + 1) + lane] : 0;
+    const int nsv = __shfl_down(segv, 1) - segv;
+    const unsigned long long kmask = __ballot(lane < K && nsv > 0);
+    const int64_t sub0 = tile_sub_start[tile];
+
+    struct It { int k, s, e; };
+    auto seek = [&](int kfrom) {  // first nonempty offset >= kfrom (K if none)
+        It it;
+        const unsigned long long rem = kfrom < 64 ? (kmask >> kfrom) << kfrom : 0ull;
+        if (rem) {
+            it.k = __builtin_amdgcn_readfirstlane(__ffsll((long long)rem) - 1);
+            it.s = __builtin_amdgcn_readlane(segv, it.k);
+            it.e = __builtin_amdgcn_readlane(segv, it.k + 1);
+        } else {
+            it.k = K; it.s = 0; it.e = 0;
+        }
+        return it;
+    };
+    auto advance = [&](It it) {
+        if (it.k >= K) return it;
+        it.s += G;
+        if (it.s >= it.e) it = seek(it.k + 1);
+        return it;
+    };
+    auto load_idx = [&](const It &it) {
+        WaveIdx<G> r;
+        r.cnt = __builtin_amdgcn_readfirstlane(it.k < K ? (it.e - it.s < G ? it.e - it.s : G) : 0);
+#pragma unroll
+        for (int m = 0; m < G; m++) {
+            const int s = m < r.cnt ? it.s + m : (it.k < K ? it.s : 0);  // clamped: never branch around a load
+            const int64_t sb = (sub0 + s) * SUB_SLOTS;
+            r.src[m] = sub_src[sb + r16];
+            r.d4[m] = *reinterpret_cast<const uint32_t *>(sub_dst + sb + 4 * g);
+        }
+        return r;
+    };
+
+    It it0 = seek(0);
+    if (it0.k < K) {
+        const int NS = CIN >> 4;  // slices per offset
+        It it1 = advance(it0), it2 = advance(it1);
+        WaveIdx<G> ix0 = load_idx(it0), ix1 = load_idx(it1), ix2 = load_idx(it2);
+        const float *wl = W + (size_t)(4 * g) * ldy + col0;  // this lane's weight rows: plane 16j + 4g + e
+        float4 a0[G];
+        float b0[4][NT];
+        {
+            int r0[G];
+#pragma unroll
+            for (int m = 0; m < G; m++) r0[m] = ix0.row(m);
+            wprefetch<NT, G>(X, wl, ldy, CIN, it0.k, 0, r0, g, r16, a0, b0);
+        }
+        __syncthreads();  // single-wave workgroup: orders the tile initialisation before the first read-modify-write
+
+        while (it0.k < K) {
+            const int kn = it1.k < K ? it1.k : it0.k;  // weights prefetched after the last slice (unused at the very end)
+            int rc[G], rn[G];
+#pragma unroll
+            for (int m = 0; m < G; m++) {
+                rc[m] = ix0.row(m);
+                rn[m] = ix1.row(m);
+            }
+#define WGROUP(MS_) wgroup<NT, G, (MS_ <= G ? MS_ : 1)>(X, wl, ldy, CIN, NS, it0.k, kn, rc, rn, ix0.d4, ix0.src, acc_tile, g, r16, a0, b0)
+            if (G == 1 || ix0.cnt == 1) WGROUP(1);
+            else if (G == 2 || ix0.cnt == 2) WGROUP(2);
+            else if (G == 3 || ix0.cnt == 3) WGROUP(3);
+            else WGROUP(4);
+#undef WGROUP
+            it0 = it1; it1 = it2; it2 = advance(it2);
+            ix0 = ix1; ix1 = ix2; ix2 = load_idx(it2);  // two groups ahead: its latency is never waited for
+        }
+    }
+    __syncthreads();
+    // epilogue: every dst row is written once, as whole float4 row segments
+    constexpr int V = NC >> 2;
+    const int64_t row0 = (int64_t)tile * TR;
+    for (int idx = lane; idx < TR * V; idx += 64) {
+        const int r = idx / V, v = idx - r * V;
+        if (row0 + r < n_dst)
+            *reinterpret_cast<float4 *>(Y + (size_t)(row0 + r) * ldy + col0 + 4 * v) =
+                *reinterpret_cast<const float4 *>(acc_tile + (size_t)r * NC + 4 * v);
+    }
+}
+
+// SEI_WAVE_PLAN="nOut:NT,TR,G[;nOut:NT,TR,G...]" overrides the default tiling of the layers with that nOut
+// (kernel experiments only)
+static bool env_wave_plan(int nOut, int *nt, int *tr, int *g) {
+    const char *e = getenv("SEI_WAVE_PLAN");
+    while (e && *e) {
+        int no = 0, a = 0, b = 0, c = 0;
+        if (sscanf(e, "%d:%d,%d,%d", &no, &a, &b, &c) == 4 && no == nOut) {
+            *nt = a; *tr = b; *g = c;
+            return true;
+        }
+        e = strchr(e, ';');
+        if (e) e++;
+    }
+    return false;
+}
+
+static bool wave_instantiated(int nt, int g) { return nt >= 1 && nt <= 8 && (g == 2 || (g == 4 && nt <= 6) || (g == 3 && nt <= 8)); }
+
+bool plan_wave(int nIn, int nOut, int K, int64_t n_dst, ConvPlan *p) {
+    if (nIn % 16 || nOut % 16 || nIn < 16 || nOut > 256 || K + 1 > 64) return false;
+    const char *kind = getenv("SEI_CONV_KERNEL");
+    if (kind && !strcmp(kind, "tile")) return false;
+    const int tiles = nOut / 16;
+    int nt = 0;
+    for (int c = 8; c >= 1; c--)
+        if (tiles % c == 0) { nt = c; break; }
+    if (nt == 1 && tiles > 1) return false;  // 11 / 13 column tiles: the workgroup-tile kernel
+    int tr = 64, g = 2;
+    int en, et, eg;
+    if (env_wave_plan(nOut, &en, &et, &eg) && en >= 1 && tiles % en == 0 && (et == 64 || et == 128 || et == 192 || et == 256) &&
+        wave_instantiated(en, eg)) {
+        nt = en; tr = et; g = eg;
+    }
+    if ((size_t)tr * nt * 16 * sizeof(float) > 64 * 1024) return false;
+    p->kind = 2; p->tile_rows = tr; p->col_group = 0; p->blocks = tiles / nt; p->nt = nt; p->g = g;
+    p->lds_bytes = (size_t)tr * nt * 16 * sizeof(float);
+    return true;
+}
+
+template <int NT, int G>
+static int launch_wave(const TiledRules &t, const ConvPlan &p, const float *X, const float *W, const float *bias, float *Y,
+                       int nIn, int nOut, const float *init, hipStream_t st) {
+    const int nwork = t.n_tiles * p.blocks;
+    conv_wave_mfma_kernel<NT, G><<<((nwork + 7) / 8) * 8, 64, p.lds_bytes, st>>>(
+        X, W, bias, Y, t.tile_sub_start, t.tile_seg, t.sub_src, t.sub_dst, t.n_dst, t.K, nIn, t.n_tiles, init, nOut,
+        p.blocks, t.tile_rows);
+    SEI_LAUNCH_CHECK();
+    return 0;
+}
+
+#define WAVE_CASE(NT_, G_) \
+    if (p.nt == NT_ && p.g == G_) return launch_wave<NT_, G_>(t, p, X, W, bias, Y, nIn, nOut, init, st);
+
+int conv_forward_wave(const TiledRules &t, const ConvPlan &p, const float *X, const float *W, const float *bias, float *Y,
+                      int nIn, int nOut, const float *init, hipStream_t st) {
+    WAVE_CASE(1, 2) WAVE_CASE(2, 2) WAVE_CASE(3, 2) WAVE_CASE(4, 2) WAVE_CASE(5, 2) WAVE_CASE(6, 2) WAVE_CASE(7, 2) WAVE_CASE(8, 2)
+    WAVE_CASE(1, 3) WAVE_CASE(2, 3) WAVE_CASE(3, 3) WAVE_CASE(4, 3) WAVE_CASE(5, 3) WAVE_CASE(6, 3) WAVE_CASE(7, 3) WAVE_CASE(8, 3)
+    WAVE_CASE(1, 4) WAVE_CASE(2, 4) WAVE_CASE(3, 4) WAVE_CASE(4, 4) WAVE_CASE(5, 4) WAVE_CASE(6, 4)
+    SEI_FAIL("conv_forward: no wave-kernel instantiation for this plan");
+}
+
+}  // namespace sei

@@ -42,7 +42,9 @@ class FlatArena:
                     seen.add(id(p))
                     params.append(p)
         self.params = params
-        total = sum(p.numel() for p in params)
+        # every parameter starts on a 256-byte boundary: the conv kernels read weights / biases with 16-byte loads
+        align = 64
+        total = sum((p.numel() + align - 1) // align * align for p in params)
         dev = params[0].device
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
@@ -52,8 +54,9 @@ class FlatArena:
             self.flat[off:off + n].copy_(p.data.reshape(-1))
             p.data = self.flat[off:off + n].view(p.shape)
             p.grad = self.grad[off:off + n].view(p.shape)
-            off += n
-        self.numel = total
+            off += (n + align - 1) // align * align
+        self.numel = total                                  # arena length (parameters + alignment padding)
+        self.n_params = sum(p.numel() for p in params)
 
     def zero_grad(self):
         self.grad.zero_()

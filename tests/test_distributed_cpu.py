@@ -25,7 +25,7 @@ def _worker(rank, world, port, out):
     torch.manual_seed(100 + rank)                      # replicas start DIFFERENT on purpose
     net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.BatchNorm1d(5), torch.nn.Linear(5, 3))
     arena = FlatArena([net])
-    assert arena.numel == sum(p.numel() for p in net.parameters())
+    assert arena.n_params == sum(p.numel() for p in net.parameters()) and arena.numel >= arena.n_params
     arena.broadcast_parameters(0)
     broadcast_buffers([net], 0)
     p0 = arena.flat.clone()
