@@ -30,6 +30,44 @@ namespace sei {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Diagnostic builds only (make EXTRA="-DSEI_STAMPS" / EXTRA="-DSEI_WAVE_ABL=n"; tools/wave_diag.sh): every wave adds
+// the s_memtime ticks it spends in each part of the kernel to g_wstamps; the ablation bits remove one cost at a time
+// (1: gathers hit the caches, 2: weights from one L1-resident slice, 4: no tile read-modify-write, 8: no MFMAs;
+// results are wrong, timing only).  The product build compiles none of it.
+#ifndef SEI_WAVE_ABL
+#define SEI_WAVE_ABL 0
+#endif
+#ifdef SEI_STAMPS
+__device__ unsigned long long g_wstamps[16];
+struct WStamp {
+    unsigned long long t, acc[16];
+    __device__ __forceinline__ WStamp() {
+        for (int i = 0; i < 16; i++) acc[i] = 0;
+        t = __builtin_amdgcn_s_memtime();
+    }
+    __device__ __forceinline__ void mark(int i) {
+        __builtin_amdgcn_sched_barrier(0);
+        unsigned long long n = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_sched_barrier(0);
+        acc[i] += n - t;
+        t = n;
+    }
+    __device__ __forceinline__ void add(int i, unsigned long long v) { acc[i] += v; }
+    __device__ __forceinline__ void flush() {
+        if (threadIdx.x == 0)
+            for (int i = 0; i < 16; i++) atomicAdd(&g_wstamps[i], acc[i]);
+    }
+};
+#define WSTAMP(i) st.mark(i)
+#define WSTAMP_ADD(i, v) st.add(i, v)
+#else
+struct WStamp {
+    __device__ __forceinline__ void flush() {}
+};
+#define WSTAMP(i)
+#define WSTAMP_ADD(i, v)
+#endif
+
 __device__ __forceinline__ f32x4 wmfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
@@ -38,7 +76,8 @@ __device__ __forceinline__ f32x4 wmfma16(float a, float b, f32x4 c) {
 // garbage, but an MFMA output row depends on its own A row only and padding slots are never written back (wrmw).
 // (A select on the loaded value would make hipcc wait for the gather right where it is issued.)
 __device__ __forceinline__ float4 wload_a(const float *__restrict__ X, int src, int CIN, int off) {
-    const uint32_t row = (uint32_t)(src > 0 ? src : 0);
+    uint32_t row = (uint32_t)(src > 0 ? src : 0);
+    if (SEI_WAVE_ABL & 1) row &= 1023u;
     return *reinterpret_cast<const float4 *>(X + (uint64_t)row * (uint32_t)CIN + off);
 }
 
@@ -118,7 +157,13 @@ __device__ __forceinline__ void wslice(const float4 (&a)[G], const float (&b)[4]
         for (int m = 0; m < MS; m++) {
             const float av = e == 0 ? a[m].x : e == 1 ? a[m].y : e == 2 ? a[m].z : a[m].w;
 #pragma unroll
-            for (int n = 0; n < NT; n++) acc[m][n] = wmfma16(av, b[e][n], acc[m][n]);
+            for (int n = 0; n < NT; n++) {
+                if (SEI_WAVE_ABL & 8) {
+                    asm volatile("" ::"v"(av), "v"(b[e][n]));  // keeps the loads alive
+                } else {
+                    acc[m][n] = wmfma16(av, b[e][n], acc[m][n]);
+                }
+            }
         }
     }
 }
@@ -130,7 +175,7 @@ __device__ __forceinline__ void wprefetch(const float *__restrict__ X, const flo
                                           float (&b)[4][NT]) {
 #pragma unroll
     for (int m = 0; m < G; m++) a[m] = wload_a(X, rows[m], CIN, 16 * j + 4 * g);
-    const float *wn = wl + ((size_t)k * CIN + 16 * j) * ldy;
+    const float *wn = (SEI_WAVE_ABL & 2) ? wl : wl + ((size_t)k * CIN + 16 * j) * ldy;
 #pragma unroll
     for (int e = 0; e < 4; e++) wload_b<NT>(wn + (size_t)e * ldy, r16, b[e]);
 }
@@ -144,7 +189,7 @@ template <int NT, int G, int MS>
 __device__ __forceinline__ void wgroup(const float *__restrict__ X, const float *__restrict__ wl, int ldy, int CIN, int NS,
                                        int kc, int kn, const int (&rc)[G], const int (&rn)[G], const uint32_t (&d4)[G],
                                        const int (&src)[G], float *acc_tile, int g, int r16, float4 (&a0)[G],
-                                       float (&b0)[4][NT]) {
+                                       float (&b0)[4][NT], WStamp &st) {
     constexpr int NC = 16 * NT;
     float4 a1[G];
     float b1[4][NT];
@@ -158,19 +203,27 @@ __device__ __forceinline__ void wgroup(const float *__restrict__ X, const float 
         wprefetch<NT, G>(X, wl, ldy, CIN, kc, j + 1, rc, g, r16, a1, b1);
         // the loads above are ISSUED before this slice's MFMAs (hipcc otherwise sinks them behind the MFMAs)
         __builtin_amdgcn_sched_barrier(0);
+        WSTAMP(1);
         wslice<NT, G, MS>(a0, b0, acc);
+        WSTAMP(2);
         const bool same = j + 2 < NS;  // else: slice 0 of the next group
         int rr[G];
 #pragma unroll
         for (int m = 0; m < G; m++) rr[m] = same ? rc[m] : rn[m];
         wprefetch<NT, G>(X, wl, ldy, CIN, same ? kc : kn, same ? j + 2 : 0, rr, g, r16, a0, b0);
         __builtin_amdgcn_sched_barrier(0);
+        WSTAMP(1);
         wslice<NT, G, MS>(a1, b1, acc);
+        WSTAMP(2);
+        WSTAMP_ADD(8, 2 * 4 * MS * NT);
     }
     if (j < NS) {  // odd slice count: the next group's slice 0 lands in the second set and is moved over
         wprefetch<NT, G>(X, wl, ldy, CIN, kn, 0, rn, g, r16, a1, b1);
         __builtin_amdgcn_sched_barrier(0);
+        WSTAMP(1);
         wslice<NT, G, MS>(a0, b0, acc);
+        WSTAMP(2);
+        WSTAMP_ADD(8, 4 * MS * NT);
 #pragma unroll
         for (int m = 0; m < G; m++) a0[m] = a1[m];
 #pragma unroll
@@ -181,8 +234,16 @@ __device__ __forceinline__ void wgroup(const float *__restrict__ X, const float 
 #pragma unroll
     for (int m = 0; m < MS; m++) {
         const int nv = __popcll(__ballot(src[m] >= 0) & 0xFFFFull);
-        wrmw<NT>(acc_tile, NC, d4[m], nv, g, r16, acc[m]);
+        if (SEI_WAVE_ABL & 4) {
+#pragma unroll
+            for (int n = 0; n < NT; n++) asm volatile("" ::"v"(acc[m][n]));
+        } else {
+            wrmw<NT>(acc_tile, NC, d4[m], nv, g, r16, acc[m]);
+        }
     }
+    WSTAMP(3);
+    WSTAMP_ADD(9, 1);
+    WSTAMP_ADD(10, MS);
 }
 
 constexpr int wave_occ(int nt, int g) {
@@ -211,6 +272,7 @@ __global__ __launch_bounds__(64, wave_occ(NT, G)) void conv_wave_mfma_kernel(
     const int col0 = cblk * NC;
     const int lane = threadIdx.x, r16 = lane & 15, g = lane >> 4;
     float *acc_tile = lds;
+    WStamp st;
 
     // accumulators start from the bias, or from the rows of `init` (Y = init + conv: gradient accumulation)
     {
@@ -278,6 +340,7 @@ __global__ __launch_bounds__(64, wave_occ(NT, G)) void conv_wave_mfma_kernel(
             wprefetch<NT, G>(X, wl, ldy, CIN, it0.k, 0, r0, g, r16, a0, b0);
         }
         __syncthreads();  // single-wave workgroup: orders the tile initialisation before the first read-modify-write
+        WSTAMP(0);
 
         while (it0.k < K) {
             const int kn = it1.k < K ? it1.k : it0.k;  // weights prefetched after the last slice (unused at the very end)
@@ -287,7 +350,7 @@ __global__ __launch_bounds__(64, wave_occ(NT, G)) void conv_wave_mfma_kernel(
                 rc[m] = ix0.row(m);
                 rn[m] = ix1.row(m);
             }
-#define WGROUP(MS_) wgroup<NT, G, (MS_ <= G ? MS_ : 1)>(X, wl, ldy, CIN, NS, it0.k, kn, rc, rn, ix0.d4, ix0.src, acc_tile, g, r16, a0, b0)
+#define WGROUP(MS_) wgroup<NT, G, (MS_ <= G ? MS_ : 1)>(X, wl, ldy, CIN, NS, it0.k, kn, rc, rn, ix0.d4, ix0.src, acc_tile, g, r16, a0, b0, st)
             if (G == 1 || ix0.cnt == 1) WGROUP(1);
             else if (G == 2 || ix0.cnt == 2) WGROUP(2);
             else if (G == 3 || ix0.cnt == 3) WGROUP(3);
@@ -295,6 +358,7 @@ __global__ __launch_bounds__(64, wave_occ(NT, G)) void conv_wave_mfma_kernel(
 #undef WGROUP
             it0 = it1; it1 = it2; it2 = advance(it2);
             ix0 = ix1; ix1 = ix2; ix2 = load_idx(it2);  // two groups ahead: its latency is never waited for
+            WSTAMP(4);
         }
     }
     __syncthreads();
@@ -307,6 +371,9 @@ __global__ __launch_bounds__(64, wave_occ(NT, G)) void conv_wave_mfma_kernel(
             *reinterpret_cast<float4 *>(Y + (size_t)(row0 + r) * ldy + col0 + 4 * v) =
                 *reinterpret_cast<const float4 *>(acc_tile + (size_t)r * NC + 4 * v);
     }
+    WSTAMP(5);
+    WSTAMP_ADD(7, 1);
+    st.flush();
 }
 
 // SEI_WAVE_PLAN="nOut:NT,TR,G[;nOut:NT,TR,G...]" overrides the default tiling of the layers with that nOut
@@ -371,3 +438,14 @@ int conv_forward_wave(const TiledRules &t, const ConvPlan &p, const float *X, co
 }
 
 }  // namespace sei
+
+#ifdef SEI_STAMPS
+extern "C" int sei_debug_wave_stamps(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(sei::g_wstamps), sizeof(sei::g_wstamps)) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(sei::g_wstamps), z, sizeof(z)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
