@@ -394,21 +394,30 @@ static bool env_wave_plan(int nOut, int *nt, int *tr, int *g) {
 
 static bool wave_instantiated(int nt, int g) { return nt >= 1 && nt <= 8 && (g == 2 || (g == 4 && nt <= 6) || (g == 3 && nt <= 8)); }
 
+// Default use: the 32- and 64-column layers (levels 0-1 of the DUNE network).  There the workgroup-tile kernel's
+// phases hold too few sub-chunks to keep four lock-stepped waves busy (structural efficiency 0.24 / 0.55) and the
+// wave kernel measured +47 % / +10 % (profiles/r02_conv_wave_sweep1.log).  From 96 columns on, the B operands of
+// this kernel (4/MS bytes per lane and MFMA through the vector-memory path, MS ~ 1.7) saturate that path --
+// profiles/r02_conv_wave_diag_L2_C96.txt: half of a wave's time goes to ISSUING loads -- and the tile kernel, whose
+// weights are shared through LDS, wins.  SEI_CONV_KERNEL=wave|tile forces one kernel (experiments).
 bool plan_wave(int nIn, int nOut, int K, int64_t n_dst, ConvPlan *p) {
     if (nIn % 16 || nOut % 16 || nIn < 16 || nOut > 256 || K + 1 > 64) return false;
     const char *kind = getenv("SEI_CONV_KERNEL");
     if (kind && !strcmp(kind, "tile")) return false;
+    const bool forced = kind && !strcmp(kind, "wave");
     const int tiles = nOut / 16;
     int nt = 0;
     for (int c = 8; c >= 1; c--)
         if (tiles % c == 0) { nt = c; break; }
     if (nt == 1 && tiles > 1) return false;  // 11 / 13 column tiles: the workgroup-tile kernel
     int tr = 64, g = 2;
+    if (nOut == 32) { tr = 128; g = 2; }
+    if (nOut == 64) { tr = 64; g = 3; }
     int en, et, eg;
-    if (env_wave_plan(nOut, &en, &et, &eg) && en >= 1 && tiles % en == 0 && (et == 64 || et == 128 || et == 192 || et == 256) &&
-        wave_instantiated(en, eg)) {
-        nt = en; tr = et; g = eg;
-    }
+    const bool env = env_wave_plan(nOut, &en, &et, &eg) && en >= 1 && tiles % en == 0 &&
+                     (et == 64 || et == 128 || et == 192 || et == 256) && wave_instantiated(en, eg);
+    if (env) { nt = en; tr = et; g = eg; }
+    if (!forced && !env && nOut != 32 && nOut != 64) return false;
     if ((size_t)tr * nt * 16 * sizeof(float) > 64 * 1024) return false;
     p->kind = 2; p->tile_rows = tr; p->col_group = 0; p->blocks = tiles / nt; p->nt = nt; p->g = g;
     p->lds_bytes = (size_t)tr * nt * 16 * sizeof(float);
