@@ -60,3 +60,58 @@ def strided_conv_dense(coords, features, spatial, batch_size, W, size, stride):
     m = active_mask(coords, spatial, batch_size).float()[:, None]
     cnt = F.conv3d(m, torch.ones(1, 1, *size), stride=stride)
     return y, cnt[:, 0] > 0
+
+
+# ----------------------------------------------------------------------------- whole encoder, dense + masks
+def _masked_bn(y, m, weight, bias, eps=1e-4):
+    """scn.BatchNormalization in training mode on a dense tensor: statistics over ACTIVE sites only (biased var)."""
+    mf = m[:, None].to(y.dtype)
+    n = mf.sum()
+    mean = (y * mf).sum(dim=(0, 2, 3, 4)) / n
+    var = (((y - mean[None, :, None, None, None]) ** 2) * mf).sum(dim=(0, 2, 3, 4)) / n
+    z = (y - mean[None, :, None, None, None]) * torch.rsqrt(var + eps)[None, :, None, None, None]
+    return (z * weight[None, :, None, None, None] + bias[None, :, None, None, None]) * mf
+
+
+def _leaky(y, leak=1.0 / 3.0):
+    return torch.where(y > 0, y, y * leak)
+
+
+def encoder_forward_dense(sd, cfg, x, image_size):
+    """Encoder.forward (/root/reference/src/networks/resnet.py:141-161) restated on DENSE tensors with active-site
+    masks and torch's own conv3d + autograd: the pin of oracle/scn_cpu.encoder_forward, forward AND backward
+    (training-mode BatchNorm, 3-D only).  Running statistics are not updated."""
+    coords, features, B = x
+    spatial = list(image_size[1:])
+    fs = cfg.filter_size
+    c = np.asarray(coords).astype(np.int64)
+    m = active_mask(c, spatial, B)
+    h = densify(c, features, spatial, B)
+
+    def conv(h, m, w, b, size):
+        y = F.conv3d(h, to_torch_kernel(w, size), padding=[s // 2 for s in size])
+        if b is not None:
+            y = y + b[None, :, None, None, None]
+        return y * m[:, None].to(y.dtype)
+
+    def series(h, m, prefix):
+        for j in range(cfg.blocks_per_layer):
+            p = "%s.block_%d" % (prefix, j)
+            res = h
+            o = conv(h, m, sd[p + ".convolution_1.conv1.weight"], sd.get(p + ".convolution_1.conv1.bias"), [fs] * 3)
+            o = _leaky(_masked_bn(o, m, sd[p + ".convolution_1.norm.weight"], sd[p + ".convolution_1.norm.bias"]))
+            o = conv(o, m, sd[p + ".convolution_2.conv1.weight"], sd.get(p + ".convolution_2.conv1.bias"), [fs] * 3)
+            o = _masked_bn(o, m, sd[p + ".convolution_2.norm.weight"], sd[p + ".convolution_2.norm.bias"])
+            h = _leaky(o + res)
+        return h
+
+    h = conv(h, m, sd["initial_convolution.weight"], sd.get("initial_convolution.bias"), [5, 5, 5])
+    for l in range(cfg.depth):
+        h = series(h, m, "network_layers.%d" % (2 * l))
+        p = "network_layers.%d" % (2 * l + 1)
+        y = F.conv3d(h, to_torch_kernel(sd[p + ".conv.weight"], [2, 2, 2]), stride=2)
+        m = F.conv3d(m.float()[:, None], torch.ones(1, 1, 2, 2, 2), stride=2)[:, 0] > 0
+        h = _leaky(_masked_bn(y * m[:, None].to(y.dtype), m, sd[p + ".norm.weight"], sd[p + ".norm.bias"]))
+    h = series(h, m, "final_layer")
+    h = conv(h, m, sd["bottleneck.weight"], sd.get("bottleneck.bias"), [1, 1, 1])
+    return torch.tanh(h)

@@ -435,14 +435,30 @@ __global__ void sparse_to_dense_kernel(const int32_t *__restrict__ coords, int64
 // ------------------------------------------------------------------ fused sparse head
 // AvgPool3d(tanh(SparseToDense(x))) over the full spatial extent == sum over ACTIVE rows of tanh(x) / V,
 // because tanh(0) = 0: the [B,C,D0,D1,D2] dense tensor never has to exist.  out[b][c] += tanh(f[row][c]) / V.
-__global__ void pool_tanh_fwd_kernel(const int32_t *__restrict__ coords, int64_t n, int C, float inv_vol,
-                                     const float *__restrict__ feats, float *__restrict__ out) {
-    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n * C) return;
-    int64_t r = t / C;
-    int c = (int)(t - r * C);
-    int b = coords[4 * r + 3];
-    atomicAdd(&out[(size_t)b * C + c], tanhf(feats[t]) * inv_vol);
+// Fixed summation order (bit-identical reruns, like every other kernel of the engine; no float atomics): the rows
+// are cut into POOL_SEGS contiguous segments, block (b, s) sums the rows of event b inside segment s in row order,
+// and the final kernel adds the segment sums in segment order.
+constexpr int POOL_SEGS = 32;
+__global__ void pool_tanh_partial_kernel(const int32_t *__restrict__ coords, int64_t n, int C,
+                                         const float *__restrict__ feats, float *__restrict__ partial) {
+    const int b = blockIdx.x, s = blockIdx.y;
+    const int64_t r0 = n * s / POOL_SEGS, r1 = n * (s + 1) / POOL_SEGS;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float acc = 0.f;
+        for (int64_t r = r0; r < r1; r++)
+            if (coords[4 * r + 3] == b) acc += tanhf(feats[r * C + c]);
+        partial[((size_t)b * POOL_SEGS + s) * C + c] = acc;
+    }
+}
+
+__global__ void pool_tanh_final_kernel(const float *__restrict__ partial, int B, int C, float inv_vol,
+                                       float *__restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * C) return;
+    const int b = t / C, c = t - b * C;
+    float acc = 0.f;
+    for (int s = 0; s < POOL_SEGS; s++) acc += partial[((size_t)b * POOL_SEGS + s) * C + c];
+    out[t] = acc * inv_vol;
 }
 
 __global__ void pool_tanh_bwd_kernel(const int32_t *__restrict__ coords, int64_t n, int C, float inv_vol,
@@ -460,14 +476,20 @@ __global__ void pool_tanh_bwd_kernel(const int32_t *__restrict__ coords, int64_t
 int pool_tanh(const Level *lv, int batch, const float *feats, int C, float *out, const float *dout, float *dfeats,
               hipStream_t st) {
     const double vol = (double)lv->spatial[0] * lv->spatial[1] * lv->spatial[2];
-    if (!dout) SEI_HIP(hipMemsetAsync(out, 0, (size_t)batch * C * sizeof(float), st));
+    if (!dout) {
+        float *partial;
+        SEI_TRY(pool_alloc_t(&partial, (size_t)batch * POOL_SEGS * C));
+        int threads = C < 64 ? 64 : (C > 1024 ? 1024 : (C + 63) / 64 * 64);
+        pool_tanh_partial_kernel<<<dim3(batch, POOL_SEGS), threads, 0, st>>>(lv->coords, lv->n, C, feats, partial);
+        pool_tanh_final_kernel<<<(batch * C + 255) / 256, 256, 0, st>>>(partial, batch, C, (float)(1.0 / vol), out);
+        pool_free(partial);
+        SEI_LAUNCH_CHECK();
+        return 0;
+    }
     if (lv->n == 0) return 0;
     int64_t tot = lv->n * C;
     unsigned nb = (unsigned)((tot + 255) / 256);
-    if (!dout)
-        pool_tanh_fwd_kernel<<<nb, 256, 0, st>>>(lv->coords, lv->n, C, (float)(1.0 / vol), feats, out);
-    else
-        pool_tanh_bwd_kernel<<<nb, 256, 0, st>>>(lv->coords, lv->n, C, (float)(1.0 / vol), feats, dout, dfeats);
+    pool_tanh_bwd_kernel<<<nb, 256, 0, st>>>(lv->coords, lv->n, C, (float)(1.0 / vol), feats, dout, dfeats);
     SEI_LAUNCH_CHECK();
     return 0;
 }

@@ -49,8 +49,10 @@ class FlatArena:
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
         off = 0
+        self._end = {}
         for p in params:
             n = p.numel()
+            self._end[id(p)] = off + (n + align - 1) // align * align
             self.flat[off:off + n].copy_(p.data.reshape(-1))
             p.data = self.flat[off:off + n].view(p.shape)
             p.grad = self.grad[off:off + n].view(p.shape)
@@ -61,11 +63,21 @@ class FlatArena:
     def zero_grad(self):
         self.grad.zero_()
 
-    def all_reduce_mean(self):
-        """Sum gradients over ranks (RCCL all-reduce over xGMI), then scale by 1/world."""
+    def offset_after(self, module):
+        """Arena offset just past the parameters of `module` (they must be a leading run of the arena)."""
+        ids = {id(p) for p in module.parameters()}
+        n = len(ids)
+        if {id(p) for p in self.params[:n]} != ids:
+            raise ValueError("module parameters are not a leading run of the arena")
+        return self._end[id(self.params[n - 1])] if n else 0
+
+    def all_reduce_mean(self, start=0):
+        """Sum gradients over ranks (RCCL all-reduce over xGMI), then scale by 1/world.  `start` > 0 skips the
+        leading (frozen) part of the arena."""
         if dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM)
-            self.grad.mul_(1.0 / dist.get_world_size())
+            g = self.grad[start:] if start else self.grad
+            dist.all_reduce(g, op=dist.ReduceOp.SUM)
+            g.mul_(1.0 / dist.get_world_size())
 
     def broadcast_parameters(self, src=0):
         if dist.is_initialized() and dist.get_world_size() > 1:

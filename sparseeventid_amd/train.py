@@ -22,6 +22,8 @@ class WarmupFlatDecay:
 
     def __init__(self, peak_learning_rate=3e-3, decay_floor=1e-3, epoch_length=100, decay_epochs=5, total_epochs=25):
         self.peak, self.floor, self.epoch_length = peak_learning_rate, decay_floor, epoch_length
+        if total_epochs is None:
+            total_epochs = 25
         self.flat_len = (total_epochs - decay_epochs - 1) * epoch_length
         self.decay_len = decay_epochs * epoch_length
 
@@ -64,14 +66,24 @@ class Trainer:
         self.encoder.to(device)
         self.head.to(device)
         self.arena = FlatArena([self.encoder, self.head])
-        self.flat_param = torch.nn.Parameter(self.arena.flat, requires_grad=True)
-        self.flat_param.grad = self.arena.grad
-        # Adam on ONE flat tensor == Adam on every parameter (elementwise), one fused kernel
-        self.opt = torch.optim.Adam([self.flat_param], lr=1.0, eps=1e-6, betas=(0.8, 0.9),
-                                    weight_decay=weight_decay, fused=torch.cuda.is_available())
+        # weight_decay default: mode.optimizer.weight_decay = 1e-6 (src/config/optimizer.py:52, the value
+        # supervised_eventID.py:201 hands to init_optimizer)
+        self.weight_decay = weight_decay
+        self._build_optimizer(0)
         self.lr_schedule = lr_schedule or WarmupFlatDecay()
         self.global_step = 0
         self.device = device
+
+    def _build_optimizer(self, start):
+        """Adam over arena[start:] as ONE flat tensor == Adam on every parameter in it (elementwise), one fused
+        kernel.  start > 0 leaves the leading (encoder) part of the arena out of the optimizer entirely: frozen
+        parameters are skipped as in the reference, where their grad is None (create_trainer.py:103-106) --
+        merely zeroing their gradient would still let weight decay shrink them (update ~ lr*wd*p/eps)."""
+        self.opt_start = start
+        self.flat_param = torch.nn.Parameter(self.arena.flat[start:], requires_grad=True)
+        self.flat_param.grad = self.arena.grad[start:]
+        self.opt = torch.optim.Adam([self.flat_param], lr=1.0, eps=1e-6, betas=(0.8, 0.9),
+                                    weight_decay=self.weight_decay, fused=torch.cuda.is_available())
 
     def to_scn_input(self, larcv_array):
         if self.cfg.data.dimension == 3:
@@ -97,7 +109,7 @@ class Trainer:
         logits = self.forward(image)
         loss = focal_loss(logits, labels)
         loss.backward()
-        self.arena.all_reduce_mean()
+        self.arena.all_reduce_mean(self.opt_start)
         for g in self.opt.param_groups:
             g["lr"] = self.lr_schedule[self.global_step]
         self.opt.step()
@@ -148,7 +160,7 @@ class Trainer:
             self.global_step = int(ck.get("global_step", 0))
             if "optimizer" in ck:
                 self.opt.load_state_dict(ck["optimizer"])
-                self.flat_param.grad = self.arena.grad
+                self.flat_param.grad = self.arena.grad[self.opt_start:]
 
     def restore_encoder_only(self, path, freeze=True):
         """mode.weights_location + restore_encoder_only (create_trainer.py:93-106): load the ``encoder.*`` keys
@@ -158,6 +170,8 @@ class Trainer:
         if freeze:
             for p in self.encoder.parameters():
                 p.requires_grad_(False)
+            # the encoder's parameters come first in the arena: optimise (and all-reduce) only what follows them
+            self._build_optimizer(self.arena.offset_after(self.encoder))
 
 
 def format_log_message(metrics, batch_size, global_step, dt=None, mode=""):

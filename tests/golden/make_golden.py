@@ -5,7 +5,9 @@
    larcvsparse_to_scnsparse_{3d,2d} (imported by file path from
    /root/reference/src/utils/core/larcvio/data_transforms.py, the torch-free twin of
    src/io/data_transforms.py:21-49,198-253): pins sparseeventid_amd.data transforms.
-2. encoder_tiny.npz -- seeded tiny network input and the ORACLE's outputs (dense encoder output,
+2. lr_schedule.npz -- values of the REFERENCE's own WarmupFlatDecay schedule (imported by file path from
+   /root/reference/src/utils/learning_rate_scheduler.py:92-126) for a few parameter sets: pins train.WarmupFlatDecay.
+3. encoder_tiny.npz -- seeded tiny network input and the ORACLE's outputs (dense encoder output,
    logits, loss).  The reference cannot produce these (its arithmetic is in the absent third-party
    `sparseconvnet`), so this fixture pins the engine + oracle against drift, not against the reference.
 """
@@ -29,7 +31,24 @@ def reference_transforms():
     return mod
 
 
+def reference_lr_schedules():
+    path = "/root/reference/src/utils/learning_rate_scheduler.py"
+    spec = importlib.util.spec_from_file_location("ref_lr_scheduler", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = {}
+    # (peak, floor, epoch_length, decay_epochs, total_epochs); the first is the reference's "standard" default
+    sets = [(3e-3, 1e-3, 100, 5, 25), (3e-3, 1e-3, 10, 5, 25), (1e-2, 1e-4, 7, 3, 6), (1e-3, 1e-5, 1, 1, None)]
+    for i, (peak, floor, el, de, te) in enumerate(sets):
+        s = mod.WarmupFlatDecay(peak_learning_rate=peak, decay_floor=floor, epoch_length=el, decay_epochs=de, total_epochs=te)
+        n = el * ((te or 25) + 2)
+        out["params_%d" % i] = np.array([peak, floor, el, de, -1 if te is None else te], np.float64)
+        out["values_%d" % i] = np.array([float(s[j]) for j in range(n)], np.float64)
+    np.savez_compressed(os.path.join(HERE, "lr_schedule.npz"), **out)
+
+
 def main():
+    reference_lr_schedules()
     ref = reference_transforms()
     rng = np.random.default_rng(20261003)
     # larcv 3-D batch [B,1,M,4] = (x,y,z,value), -999 padded, ragged fill levels incl. an empty event

@@ -82,14 +82,31 @@ def test_encoder_head_loss_parity(dimension, image_size, kw):
         assert rel_err(b, osd[k]) < 1e-4, k
 
 
-def test_fused_sparse_head_equals_dense_path():
-    """Opt-in fused head: sum_active tanh(x)/V == AvgPool3d(tanh(SparseToDense(x)))."""
+def test_fused_sparse_head_equals_dense_path_and_oracle():
+    """Opt-in fused head: sum_active tanh(x)/V == AvgPool3d(tanh(SparseToDense(x))) -- against the
+    engine's own dense path AND against the oracle (pooled activations, logits, bottleneck gradient), and
+    bit-identical between two runs (fixed-order reduction, no float atomics)."""
     torch.manual_seed(1)
     kw = dict(depth=2, n_initial_filters=16, n_output_filters=16, blocks_per_layer=1)
     enc, head = _build(kw, [1, 32, 32, 32])
     enc.train(); head.eval()
     coords, feats = blob_cloud(9, 3, [32, 32, 32], 300, 1)
     x = (torch.from_numpy(coords), torch.from_numpy(feats), 3)
+    # oracle leg: same weights, dense oracle encoder -> spatial mean -> oracle head
+    sd = {k: v.detach().cpu().clone() for k, v in enc.state_dict().items()}
+    sd.update({k: v.detach().cpu().clone() for k, v in head.state_dict().items()})
+    osd = {k: (v.requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v) for k, v in sd.items()}
+    ocfg = scn_cpu.NetConfig(**kw)
+    odense = scn_cpu.encoder_forward(osd, ocfg, (coords, torch.from_numpy(feats), 3), [1, 32, 32, 32])
+    ologits = scn_cpu.head_forward(osd, odense, HEADS)
+    sum(v.square().sum() for v in ologits.values()).backward()
+    with torch.no_grad():
+        p1 = enc.forward_pooled(x)
+        p2 = enc.forward_pooled(x)
+    # BN running statistics moved between the two calls but training-mode outputs do not depend on them
+    assert torch.equal(p1, p2)
+    assert rel_err(p1[:, :, 0, 0, 0], odense.mean(dim=(2, 3, 4))) < 1e-4
+    enc.load_state_dict({k: v for k, v in sd.items() if not k.startswith("classification_head")})  # reset BN buffers
     dense_logits = head(enc(x))
     loss_d = sum(v.square().sum() for v in dense_logits.values())
     loss_d.backward()
@@ -100,4 +117,6 @@ def test_fused_sparse_head_equals_dense_path():
     loss_f.backward()
     for k in HEADS:
         assert rel_err(fused_logits[k], dense_logits[k]) < 1e-5
+        assert rel_err(fused_logits[k], ologits[k]) < 1e-4
     assert rel_err(enc.bottleneck.weight.grad, g_dense) < 1e-4
+    assert rel_err(enc.bottleneck.weight.grad, osd["bottleneck.weight"].grad) < 1e-4

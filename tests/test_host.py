@@ -57,6 +57,22 @@ def test_synthetic_event_contract():
     assert c.shape == (4000, 4) and b == 2
 
 
+def test_lr_schedule_matches_reference_fixture():
+    """tests/golden/lr_schedule.npz holds values produced by the REFERENCE's WarmupFlatDecay
+    (/root/reference/src/utils/learning_rate_scheduler.py:92-126, imported by tests/golden/make_golden.py)."""
+    from sparseeventid_amd.train import WarmupFlatDecay
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lr_schedule.npz"))
+    n_sets = sum(1 for k in g.files if k.startswith("params_"))
+    assert n_sets >= 4
+    for i in range(n_sets):
+        peak, floor, el, de, te = g["params_%d" % i]
+        s = WarmupFlatDecay(peak_learning_rate=float(peak), decay_floor=float(floor), epoch_length=int(el),
+                            decay_epochs=int(de), total_epochs=None if te < 0 else int(te))
+        want = g["values_%d" % i]
+        got = np.array([s[j] for j in range(len(want))])
+        assert np.allclose(got, want, rtol=1e-12, atol=1e-15), i
+
+
 def test_lr_schedule_matches_reference_formula():
     from sparseeventid_amd.train import WarmupFlatDecay
     s = WarmupFlatDecay(peak_learning_rate=3e-3, decay_floor=1e-3, epoch_length=10, decay_epochs=5, total_epochs=25)
@@ -114,4 +130,15 @@ def test_checkpoint_roundtrip_and_encoder_only_restore(tmp_path):
     assert torch.equal(c.encoder.initial_convolution.weight, a.encoder.initial_convolution.weight)
     assert torch.equal(c.head.state_dict()["classification_head.labelneutID.2.weight"], head_before)
     assert all(not p.requires_grad for p in c.encoder.parameters())
+    # frozen means FROZEN: an optimizer step (weight decay 1e-6, eps 1e-6) leaves every encoder tensor bit-identical
+    # and still moves the head (advisor finding, round 1: Adam on the whole arena shrank the "frozen" encoder)
+    enc_before = {k: v.clone() for k, v in c.encoder.state_dict().items()}
+    c.arena.grad.zero_()
+    for p in c.head.parameters():
+        p.grad.normal_()
+    for g in c.opt.param_groups:
+        g["lr"] = 3e-3
+    c.opt.step()
+    assert all(torch.equal(v, enc_before[k]) for k, v in c.encoder.state_dict().items())
+    assert not torch.equal(c.head.state_dict()["classification_head.labelneutID.2.weight"], head_before)
     assert "Img/s" in format_log_message({"loss/loss": 1.25}, 64, 3, dt=0.5, mode="train")
