@@ -130,6 +130,7 @@ def main():
     image_size = [1] + list(grid)
     tr = Trainer(image_size=image_size, device="cuda", seed=0, model="sbnd" if args.model == "sbnd" else "resnet")
     tr.arena.broadcast_parameters()
+    tr.buffers.broadcast()
     image, lab = tr.stage(tr.to_scn_input(arr), labels)   # inputs resident in HBM before timing
 
     def step():
@@ -159,10 +160,26 @@ def main():
     dt = time.perf_counter() - t0
     lib.sei_prof_enable(0)
     ms = dt / args.steps * 1e3
+    sync = None
     if world > 1:
         t = torch.tensor([ms], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         ms = float(t.item())
+        # data-parallel invariants, checked AFTER the timed region: every rank ended with bit-identical parameters
+        # (elementwise max == min over ranks) and every rank trained on a different batch
+        if args.mode == "train":
+            lo, hi = tr.arena.flat.clone(), tr.arena.flat.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            if not torch.equal(lo, hi):
+                raise SystemExit("rank %d: parameters differ across ranks after %d steps" % (rank, args.steps + args.warmup))
+        sig = torch.tensor([float(np.asarray(arr, dtype=np.float64).sum())], device="cuda", dtype=torch.float64)
+        sigs = [torch.zeros_like(sig) for _ in range(world)]
+        dist.all_gather(sigs, sig)
+        if len({float(x.item()) for x in sigs}) != world:
+            raise SystemExit("ranks were given identical batches")
+        sync = {"parameters_bit_identical_across_ranks": args.mode == "train", "distinct_batches": True,
+                "backend": args.backend, "one_device": bool(args.one_device)}
 
     if rank == 0:
         import ctypes
@@ -216,6 +233,8 @@ def main():
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world},
             "roofline": roof, "cpu_baseline": cpu,
         }
+        if sync is not None:
+            out["data_parallel_checks"] = sync
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -84,6 +84,34 @@ class FlatArena:
             dist.broadcast(self.flat, src=src)
 
 
+class FlatBuffers:
+    """All floating-point buffers (BatchNorm running statistics) of a set of modules as views into ONE contiguous
+    tensor, so that what DDP's ``broadcast_buffers=True`` does before every forward (rank 0's buffers to every
+    rank; torch default, create_trainer.py:50-58 builds DDP with it) is a single small broadcast."""
+
+    def __init__(self, modules):
+        bufs, seen = [], set()
+        for m in modules:
+            for b in m.buffers():
+                if b.dtype == torch.float32 and id(b) not in seen:
+                    seen.add(id(b))
+                    bufs.append(b)
+        self.bufs = bufs
+        self.flat = None
+        if bufs:
+            self.flat = torch.zeros(sum(b.numel() for b in bufs), dtype=torch.float32, device=bufs[0].device)
+            off = 0
+            for b in bufs:
+                n = b.numel()
+                self.flat[off:off + n].copy_(b.data.reshape(-1))
+                b.data = self.flat[off:off + n].view(b.shape)
+                off += n
+
+    def broadcast(self, src=0):
+        if self.flat is not None and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.broadcast(self.flat, src=src)
+
+
 def broadcast_buffers(modules, src=0):
     """What DDP's broadcast_buffers does for the BN running statistics."""
     if not (dist.is_initialized() and dist.get_world_size() > 1):

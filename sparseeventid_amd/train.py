@@ -12,7 +12,7 @@ import torch
 
 from .config import IMAGE_SIZE, OUTPUT_SHAPE, Config
 from .data import larcvsparse_to_scnsparse_2d, larcvsparse_to_scnsparse_3d
-from .distributed import FlatArena
+from .distributed import FlatArena, FlatBuffers
 from .loss import accuracy, focal_loss
 from .networks import build_networks
 
@@ -66,6 +66,7 @@ class Trainer:
         self.encoder.to(device)
         self.head.to(device)
         self.arena = FlatArena([self.encoder, self.head])
+        self.buffers = FlatBuffers([self.encoder, self.head])
         # weight_decay default: mode.optimizer.weight_decay = 1e-6 (src/config/optimizer.py:52, the value
         # supervised_eventID.py:201 hands to init_optimizer)
         self.weight_decay = weight_decay
@@ -106,6 +107,7 @@ class Trainer:
     def train_step(self, image, labels):
         """forward + focal loss + backward + gradient all-reduce + Adam step. Returns loss tensor."""
         self.arena.zero_grad()
+        self.buffers.broadcast()   # DDP broadcast_buffers=True: rank 0's BN running statistics before every forward
         logits = self.forward(image)
         loss = focal_loss(logits, labels)
         loss.backward()

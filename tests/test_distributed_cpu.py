@@ -19,7 +19,7 @@ def _free_port():
 def _worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
-    from sparseeventid_amd.distributed import FlatArena, broadcast_buffers, init_from_env
+    from sparseeventid_amd.distributed import FlatArena, FlatBuffers, broadcast_buffers, init_from_env
     r, w, _ = init_from_env("gloo")
     assert (r, w) == (rank, world)
     torch.manual_seed(100 + rank)                      # replicas start DIFFERENT on purpose
@@ -46,6 +46,15 @@ def _worker(rank, world, port, out):
     dist.all_gather(flats, arena.flat)
     assert torch.equal(flats[0], flats[1])             # replicas stay identical
     assert not torch.equal(arena.flat, p0)
+    # DDP broadcast_buffers semantics through ONE flat broadcast: the ranks' BN running statistics have diverged
+    # (different shards); after the broadcast every rank holds rank 0's
+    fb = FlatBuffers([net])
+    assert net[1].running_mean.data_ptr() == fb.flat.data_ptr()
+    mine = net[1].running_var.clone()
+    fb.broadcast(0)
+    rv = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(rv, net[1].running_var)
+    assert torch.equal(rv[0], rv[1]) and (rank == 0) == torch.equal(mine, net[1].running_var)
     out.put((rank, float(arena.flat.sum())))
     dist.barrier()
     dist.destroy_process_group()
