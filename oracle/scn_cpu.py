@@ -55,6 +55,57 @@ def _p(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
+# ----------------------------------------------------------------------------- C++/OpenMP backend (CPU baseline)
+_OMP = None
+_BACKEND = "torch"
+
+
+def build_omp_lib(force=False):
+    """Compile oracle/scn_omp.cpp (g++ -O3 -fopenmp; building the baseline is not using it)."""
+    so = os.path.join(_HERE, "liboracle_omp.so")
+    src = os.path.join(_HERE, "scn_omp.cpp")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["g++", "-O3", "-std=c++17", "-fopenmp", "-fPIC", "-shared", "-o", so, src, "-ldl"])
+    return so
+
+
+def _omp():
+    global _OMP
+    if _OMP is None:
+        import glob
+        lib = ctypes.CDLL(build_omp_lib())
+        lib.omp_subm_rules.restype = ctypes.c_int64
+        lib.omp_load_blas.restype = ctypes.c_int
+        blas = None
+        try:      # the OpenBLAS inside the scipy wheel (symbols prefixed scipy_)
+            import scipy
+            cand = glob.glob(os.path.join(os.path.dirname(scipy.__file__), "..", "scipy.libs", "libscipy_openblas-*.so"))
+            if cand and lib.omp_load_blas(cand[0].encode(), b"scipy_") == 0:
+                blas = cand[0]
+        except ImportError:
+            pass
+        lib.blas_path = blas   # None: plain-loop sgemm (slow; only for boxes without scipy)
+        _OMP = lib
+    return _OMP
+
+
+def use_backend(name, threads=None):
+    """'torch' (default: the checker of every parity test) or 'omp' (C++/OpenMP inner loops: bench.py's cpu_baseline)."""
+    global _BACKEND
+    if name not in ("torch", "omp"):
+        raise ValueError(name)
+    if name == "omp":
+        lib = _omp()
+        if threads:
+            lib.omp_set_threads(int(threads))
+    _BACKEND = name
+
+
+def omp_info():
+    lib = _omp()
+    return {"threads": int(lib.omp_threads()), "blas": lib.blas_path}
+
+
 def _triple(v):
     if isinstance(v, torch.Tensor):
         v = v.tolist()
@@ -103,10 +154,10 @@ def subm_rules(coords, spatial_size, filter_size):
     cap = max(n * K, 1)
     # first try a modest capacity, regrow if needed
     cap_try = max(n * min(K, 32), 1)
+    fn = _omp().omp_subm_rules if _BACKEND == "omp" else _lib().oracle_subm_rules
     while True:
         ri = np.empty(cap_try, np.int32); ro = np.empty(cap_try, np.int32)
-        tot = _lib().oracle_subm_rules(_p(coords), ctypes.c_int64(n), _p(sp), _p(f), _p(start),
-                                       _p(ri), _p(ro), ctypes.c_int64(cap_try))
+        tot = fn(_p(coords), ctypes.c_int64(n), _p(sp), _p(f), _p(start), _p(ri), _p(ro), ctypes.c_int64(cap_try))
         if tot <= cap_try:
             break
         cap_try = min(cap, int(tot))
@@ -188,7 +239,39 @@ class _RuleConv(torch.autograd.Function):
         return dx, dW, None, None, None, None
 
 
+class _RuleConvOMP(torch.autograd.Function):
+    """The same three loops in C++/OpenMP (oracle/scn_omp.cpp): blocks of rules, gather -> sgemm -> scatter-add."""
+
+    @staticmethod
+    def forward(ctx, x, W, start, ri, ro, n_out):
+        x = x.contiguous(); W = W.contiguous()
+        out = torch.zeros(n_out, W.shape[2], dtype=torch.float32)
+        start = np.ascontiguousarray(start, dtype=np.int64)
+        _omp().omp_conv_fwd(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(W.data_ptr()), _p(start), _p(ri), _p(ro),
+                            ctypes.c_int(W.shape[0]), ctypes.c_int(W.shape[1]), ctypes.c_int(W.shape[2]),
+                            ctypes.c_void_p(out.data_ptr()))
+        ctx.save_for_backward(x, W)
+        ctx.rules = (start, ri, ro)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, W = ctx.saved_tensors
+        start, ri, ro = ctx.rules
+        dout = dout.contiguous()
+        dx = torch.zeros_like(x) if ctx.needs_input_grad[0] else None
+        dW = torch.empty_like(W)
+        _omp().omp_conv_bwd(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(W.data_ptr()), ctypes.c_void_p(dout.data_ptr()),
+                            _p(start), _p(ri), _p(ro), ctypes.c_int(W.shape[0]), ctypes.c_int(W.shape[1]),
+                            ctypes.c_int(W.shape[2]), ctypes.c_void_p(dx.data_ptr()) if dx is not None else None,
+                            ctypes.c_void_p(dW.data_ptr()))
+        return dx, dW, None, None, None, None
+
+
 def _apply_rules(x, W, start, ri, ro, n_out):
+    if _BACKEND == "omp" and x.dtype == torch.float32:
+        return _RuleConvOMP.apply(x, W, start, np.ascontiguousarray(ri, dtype=np.int32),
+                                  np.ascontiguousarray(ro, dtype=np.int32), n_out)
     ri_t = torch.from_numpy(ri.astype(np.int64)); ro_t = torch.from_numpy(ro.astype(np.int64))
     return _RuleConv.apply(x, W, start, ri_t, ro_t, n_out)
 
@@ -217,10 +300,68 @@ def strided_conv(t, weight, bias, size, stride):
     return OracleTensor(out, oc, osp, t.batch_size, {})
 
 
+class _BatchNormOMP(torch.autograd.Function):
+    """Training-mode BatchNorm (+ LeakyReLU slope) as two OpenMP passes over the rows (oracle/scn_omp.cpp)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, leak):
+        x = x.contiguous()
+        n, C = x.shape
+        y = torch.empty_like(x)
+        mean, invstd, var = torch.empty(C), torch.empty(C), torch.empty(C)
+        vp = lambda t: ctypes.c_void_p(t.data_ptr())
+        _omp().omp_bn_fwd(vp(x), ctypes.c_int64(n), ctypes.c_int(C), vp(weight.contiguous()), vp(bias.contiguous()),
+                          ctypes.c_float(eps), ctypes.c_float(leak), vp(y), vp(mean), vp(invstd), vp(var))
+        ctx.save_for_backward(x, y, weight, mean, invstd)
+        ctx.leak = leak
+        ctx.mark_non_differentiable(mean, var)
+        return y, mean, var
+
+    @staticmethod
+    def backward(ctx, dy, _dm, _dv):
+        x, y, weight, mean, invstd = ctx.saved_tensors
+        n, C = x.shape
+        dy = dy.contiguous()
+        dx, dg, db = torch.empty_like(x), torch.empty(C), torch.empty(C)
+        vp = lambda t: ctypes.c_void_p(t.data_ptr())
+        _omp().omp_bn_bwd(vp(x), vp(y), vp(dy), ctypes.c_int64(n), ctypes.c_int(C), vp(weight.contiguous()), vp(mean),
+                          vp(invstd), ctypes.c_float(ctx.leak), vp(dx), vp(dg), vp(db))
+        return dx, dg, db, None, None
+
+
+class _LeakyOMP(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, leak):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        _omp().omp_leaky(ctypes.c_void_p(x.data_ptr()), None, ctypes.c_int64(x.numel()), ctypes.c_float(leak),
+                         ctypes.c_void_p(y.data_ptr()))
+        ctx.save_for_backward(y)
+        ctx.leak = leak
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(y)
+        _omp().omp_leaky(ctypes.c_void_p(y.data_ptr()), ctypes.c_void_p(dy.data_ptr()), ctypes.c_int64(y.numel()),
+                         ctypes.c_float(ctx.leak), ctypes.c_void_p(dx.data_ptr()))
+        return dx, None
+
+
 def batchnorm(t, weight, bias, running_mean=None, running_var=None, eps=1e-4, momentum=0.9,
               training=True, leakiness=1.0):
     """scn.BatchNormalization (sparse_building_blocks.py:39,122): stats over all active rows."""
     x = t.features
+    if (_BACKEND == "omp" and training and weight is not None and x.dtype == torch.float32 and x.shape[0] > 0):
+        y, mean, var = _BatchNormOMP.apply(x, weight, bias, float(eps), float(leakiness))
+        if running_mean is not None:
+            n = x.shape[0]
+            with torch.no_grad():
+                running_mean.mul_(momentum).add_((1 - momentum) * mean)
+                running_var.mul_(momentum).add_((1 - momentum) * var * n / max(n - 1, 1))
+        return t.like(y)
     if training:
         mean = x.mean(0)
         var = ((x - mean) ** 2).mean(0)
@@ -242,6 +383,8 @@ def batchnorm(t, weight, bias, running_mean=None, running_var=None, eps=1e-4, mo
 def leaky_relu(t, leak=1.0 / 3.0):
     """scn.LeakyReLU(leak=1/3) (sparse_building_blocks.py:20,80,128)."""
     x = t.features
+    if _BACKEND == "omp" and x.dtype == torch.float32:
+        return t.like(_LeakyOMP.apply(x, float(leak)))
     return t.like(torch.where(x > 0, x, x * leak))
 
 
