@@ -197,6 +197,24 @@ def main():
         sync = {"parameters_bit_identical_across_ranks": args.mode == "train", "distinct_batches": True,
                 "backend": args.backend, "one_device": bool(args.one_device)}
 
+    staging = None
+    if world == 1 and args.mode == "train" and args.model == "dune3d":
+        # the same step INCLUDING input staging: pinned host larcv block -> H2D -> device-side transform
+        # (Trainer.stage_larcv) -> step.  Reported beside `value`, never as `value` (inputs resident is the metric).
+        pinned = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)).pin_memory()
+        k2 = max(1, min(args.steps, 5))
+        img2, lab2 = tr.stage_larcv(pinned, labels)
+        tr.train_step(img2, lab2)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(k2):
+            img2, lab2 = tr.stage_larcv(pinned, labels)
+            tr.train_step(img2, lab2)
+        torch.cuda.synchronize()
+        ms2 = (time.perf_counter() - t1) / k2 * 1e3
+        staging = {"ms_per_step": ms2, "events_per_s": args.batch / (ms2 * 1e-3), "steps": k2,
+                   "path": "pinned host larcv fp32 [B,1,M,4] -> H2D -> sei_larcv_to_scn on the device -> train step"}
+
     if rank == 0:
         import ctypes
         roof = None
@@ -251,6 +269,8 @@ def main():
         }
         if sync is not None:
             out["data_parallel_checks"] = sync
+        if staging is not None:
+            out["staging_inclusive"] = staging
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -11,10 +11,16 @@ void set_error(const std::string &msg) { g_error = msg; }
 
 // ---------------------------------------------------------------- pool
 namespace {
+struct PoolBlock {
+    size_t size;
+    int device;
+    hipStream_t stream;
+};
+typedef std::pair<int, hipStream_t> PoolKey;
 struct Pool {
     std::mutex mu;
-    std::multimap<size_t, void *> free_blocks;
-    std::map<void *, size_t> live;
+    std::map<PoolKey, std::multimap<size_t, void *>> free_blocks;
+    std::map<void *, PoolBlock> live;
     size_t held = 0, in_use = 0;
 } g_pool;
 
@@ -28,29 +34,37 @@ size_t round_size(size_t b) {
     const size_t g = 1u << 20;  // 1 MiB granules above
     return (b + g - 1) / g * g;
 }
+
+void release_cached_locked() {
+    for (auto &kv : g_pool.free_blocks)
+        for (auto &b : kv.second) {
+            (void)hipFree(b.second);
+            g_pool.held -= b.first;
+        }
+    g_pool.free_blocks.clear();
+}
 }  // namespace
 
-void *pool_alloc(size_t bytes) {
+void *pool_alloc(size_t bytes, hipStream_t st) {
     size_t sz = round_size(bytes);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lk(g_pool.mu);
-    auto it = g_pool.free_blocks.lower_bound(sz);
-    if (it != g_pool.free_blocks.end() && it->first <= sz + sz / 4 + (1u << 20)) {
+    auto &fl = g_pool.free_blocks[PoolKey(dev, st)];
+    auto it = fl.lower_bound(sz);
+    if (it != fl.end() && it->first <= sz + sz / 4 + (1u << 20)) {
         void *p = it->second;
         size_t got = it->first;
-        g_pool.free_blocks.erase(it);
-        g_pool.live[p] = got;
+        fl.erase(it);
+        g_pool.live[p] = PoolBlock{got, dev, st};
         g_pool.in_use += got;
         return p;
     }
     void *p = nullptr;
     hipError_t e = hipMalloc(&p, sz);
     if (e != hipSuccess) {
-        // release cached blocks and retry once
-        for (auto &kv : g_pool.free_blocks) {
-            (void)hipFree(kv.second);
-            g_pool.held -= kv.first;
-        }
-        g_pool.free_blocks.clear();
+        // release cached blocks (all streams: the allocator call itself synchronises) and retry once
+        release_cached_locked();
         (void)hipGetLastError();
         e = hipMalloc(&p, sz);
         if (e != hipSuccess) {
@@ -60,7 +74,7 @@ void *pool_alloc(size_t bytes) {
     }
     g_pool.held += sz;
     g_pool.in_use += sz;
-    g_pool.live[p] = sz;
+    g_pool.live[p] = PoolBlock{sz, dev, st};
     return p;
 }
 
@@ -69,9 +83,24 @@ void pool_free(void *p) {
     std::lock_guard<std::mutex> lk(g_pool.mu);
     auto it = g_pool.live.find(p);
     if (it == g_pool.live.end()) return;
-    g_pool.free_blocks.emplace(it->second, p);
-    g_pool.in_use -= it->second;
+    const PoolBlock b = it->second;
+    g_pool.free_blocks[PoolKey(b.device, b.stream)].emplace(b.size, p);
+    g_pool.in_use -= b.size;
     g_pool.live.erase(it);
+}
+
+int ensure_max_lds(const void *kernel, int bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<int, const void *>, int> done;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(mu);
+    auto key = std::make_pair(dev, kernel);
+    auto it = done.find(key);
+    if (it != done.end() && it->second >= bytes) return 0;
+    SEI_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done[key] = bytes;
+    return 0;
 }
 
 // ---------------------------------------------------------------- profiling
@@ -204,6 +233,7 @@ int sei_input_features_bwd(sei_metadata_t *m, const float *dout, int32_t C, floa
 }
 
 int sei_level_rows(sei_metadata_t *m, const int32_t spatial[3], int64_t *n_rows) {
+    if (!m || !spatial || !n_rows) SEI_FAIL("sei_level_rows: null argument");
     std::lock_guard<std::mutex> lk(m->mu);
     Level *l = find_level(m, spatial);
     if (!l) SEI_FAIL("no level with this spatial size in the metadata");
@@ -212,6 +242,7 @@ int sei_level_rows(sei_metadata_t *m, const int32_t spatial[3], int64_t *n_rows)
 }
 
 int sei_level_coords(sei_metadata_t *m, const int32_t spatial[3], int32_t *coords_out_dev, sei_stream_t stream) {
+    if (!m || !spatial) SEI_FAIL("sei_level_coords: null argument");
     std::lock_guard<std::mutex> lk(m->mu);
     Level *l = find_level(m, spatial);
     if (!l) SEI_FAIL("no level with this spatial size in the metadata");
@@ -222,6 +253,7 @@ int sei_level_coords(sei_metadata_t *m, const int32_t spatial[3], int32_t *coord
 }
 
 int sei_batch_size(sei_metadata_t *m, int32_t *batch_size) {
+    if (!m || !batch_size) SEI_FAIL("sei_batch_size: null argument");
     *batch_size = m->batch_size;
     return 0;
 }
@@ -322,7 +354,7 @@ struct AlignedArg {
     int stage(const float *src, size_t count, hipStream_t st) {
         p = src;
         if (!src || ((uintptr_t)src & 15) == 0) return 0;
-        SEI_TRY(pool_alloc_t(&tmp, count));
+        SEI_TRY(pool_alloc_t(&tmp, count, st));
         SEI_HIP(hipMemcpyAsync(tmp, src, count * sizeof(float), hipMemcpyDeviceToDevice, st));
         p = tmp;
         return 0;
@@ -353,7 +385,7 @@ int sei_conv_forward(sei_rulebook_t *rb, const float *X, const float *W, const f
     }
     // the workgroup-tile MFMA kernel reads B operands with wide LDS loads from column-permuted weights (tiny copy, <= 4 MB)
     float *Wp;
-    SEI_TRY(pool_alloc_t(&Wp, (size_t)t->K * nIn * nOut));
+    SEI_TRY(pool_alloc_t(&Wp, (size_t)t->K * nIn * nOut, st));
     int rc = conv_transform_weights(W, Wp, t->K, nIn, nOut, false, false, p.col_group, p.blocks, st);
     if (!rc) {
         ProfScope ps(PROF_CONV_FWD, st, 2.0 * t->n_rules * nIn * nOut, conv_bytes(*t, nIn, nOut));
@@ -375,7 +407,7 @@ static int conv_backward_input_impl(sei_rulebook_t *rb, const float *dY, const f
     if (dX_init && (p.kind == 0 || t->n_sub == 0))
         SEI_FAIL("conv_backward_input_accumulate: not supported for these plane counts");
     float *Wt;
-    SEI_TRY(pool_alloc_t(&Wt, (size_t)t->K * nIn * nOut));
+    SEI_TRY(pool_alloc_t(&Wt, (size_t)t->K * nIn * nOut, st));
     // Wt[k'][co][ci] = W[K-1-k' (submanifold mirror) or k'][ci][co] (kind 1: columns (ci) permuted for the kernel)
     int rc = conv_transform_weights(W, Wt, t->K, nIn, nOut, true, rb->submanifold, p.kind == 1 ? p.col_group : 0,
                                     p.kind == 1 ? p.blocks : 1, st);
@@ -497,11 +529,7 @@ int sei_pool_stats(int64_t *bytes_held, int64_t *bytes_in_use) {
 }
 int sei_pool_trim(void) {
     std::lock_guard<std::mutex> lk(g_pool.mu);
-    for (auto &kv : g_pool.free_blocks) {
-        (void)hipFree(kv.second);
-        g_pool.held -= kv.first;
-    }
-    g_pool.free_blocks.clear();
+    release_cached_locked();
     return 0;
 }
 

@@ -36,20 +36,25 @@ void set_error(const std::string &msg);
 #define SEI_LAUNCH_CHECK() SEI_HIP(hipGetLastError())
 
 // ---------------------------------------------------------------- device memory pool
-// Library-owned memory (hash tables, rulebooks, scratch).  Blocks are recycled on free so
-// the steady state of a training loop performs no hipMalloc.  All users enqueue on one
-// stream (torch's current stream), so reuse is stream-ordered.
-void *pool_alloc(size_t bytes);
+// Library-owned memory (hash tables, rulebooks, scratch).  Blocks are recycled on free so the steady state of a
+// training loop performs no hipMalloc.  Every block remembers the (device, stream) it was allocated for and is
+// handed out again ONLY to allocations on that same device and stream: a scratch block freed right after an
+// asynchronous launch is therefore reused in stream order (safe), while work on another stream or device gets
+// memory of its own instead of aliasing it.
+void *pool_alloc(size_t bytes, hipStream_t st);
 void pool_free(void *p);
 template <typename T>
-inline int pool_alloc_t(T **out, size_t count) {
-    *out = (T *)pool_alloc(count * sizeof(T) + 16);
+inline int pool_alloc_t(T **out, size_t count, hipStream_t st) {
+    *out = (T *)pool_alloc(count * sizeof(T) + 16, st);
     if (!*out) {
         set_error("device pool: out of memory");
         return 1;
     }
     return 0;
 }
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (device, kernel); thread-safe (autograd calls in from a
+// second thread)
+int ensure_max_lds(const void *kernel, int bytes);
 
 // ---------------------------------------------------------------- hashing (device + host identical)
 constexpr uint64_t EMPTY_KEY = 0xFFFFFFFFFFFFFFFFull;

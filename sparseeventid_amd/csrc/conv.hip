@@ -374,13 +374,8 @@ __global__ void slab_reduce_kernel(const float *__restrict__ slab, float *__rest
 template <int MT, int NT>
 static int launch_dw(const TiledRules &t, const float *X, const float *dY, int nIn, int nOut, int tps, int S,
                      float *slab, hipStream_t st) {
-    static bool attr_set = false;
     size_t lds_bytes = (size_t)MT * 16 * nOut * sizeof(float);
-    if (!attr_set) {
-        SEI_HIP(hipFuncSetAttribute((const void *)conv_dw_mfma_kernel<MT, NT>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        attr_set = true;
-    }
+    SEI_TRY(ensure_max_lds((const void *)conv_dw_mfma_kernel<MT, NT>, 128 * 1024));
     // 8 * (ci blocks) * K * ceil(S/8) linear ids, decoded in the kernel
     dim3 grid(8 * (nIn / (16 * MT)) * t.K * ((S + 7) / 8), 1, 1);
     conv_dw_mfma_kernel<MT, NT><<<grid, 256, lds_bytes, st>>>(X, dY, t.tile_sub_start, t.seg_start, t.sub_src, t.sub_dst,
@@ -450,7 +445,7 @@ int conv_backward_weight(const TiledRules &t, const float *X, const float *dY, f
     tps = (t.n_tiles + S - 1) / S;
     S = (t.n_tiles + tps - 1) / tps;
     float *slab;
-    SEI_TRY(pool_alloc_t(&slab, (size_t)t.K * S * per));
+    SEI_TRY(pool_alloc_t(&slab, (size_t)t.K * S * per, st));
     int rc = 0;
     dim3 grid(t.K, S, 1);
     if (mfma_ok)

@@ -525,12 +525,7 @@ ConvPlan plan_conv(int nIn, int nOut, int K, int64_t n_dst) {
 template <int NT, int CS, int SLJ, int MAXS>
 static int launch_mfma(const TiledRules &t, const ConvPlan &p, const float *X, const float *W, const float *bias,
                        float *Y, int nIn, const float *init, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        SEI_HIP(hipFuncSetAttribute((const void *)conv_tile_mfma_kernel<NT, CS, SLJ, MAXS>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    SEI_TRY(ensure_max_lds((const void *)conv_tile_mfma_kernel<NT, CS, SLJ, MAXS>, 160 * 1024));
     conv_tile_mfma_kernel<NT, CS, SLJ, MAXS><<<((t.n_tiles * p.blocks + 7) / 8) * 8, 256, p.lds_bytes, st>>>(
         X, W, bias, Y, t.tile_sub_start, t.tile_seg, t.sub_src, t.sub_dst, t.n_dst, t.K, nIn, t.n_tiles, init,
         NT * CS * 16 * p.blocks, p.blocks);
@@ -579,12 +574,7 @@ int conv_forward(const TiledRules &t, const float *X, const float *W, const floa
         if (lds_small <= 160 * 1024) {
 #define SMF(CIN_, COUT_)                                                                                           \
     do {                                                                                                           \
-        static bool a_ = false;                                                                                    \
-        if (!a_) {                                                                                                 \
-            SEI_HIP(hipFuncSetAttribute((const void *)conv_tile_smallcin_kernel<CIN_, COUT_>,                      \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                 \
-            a_ = true;                                                                                             \
-        }                                                                                                          \
+        SEI_TRY(ensure_max_lds((const void *)conv_tile_smallcin_kernel<CIN_, COUT_>, 160 * 1024));                 \
         conv_tile_smallcin_kernel<CIN_, COUT_><<<t.n_tiles, 256, lds_small, st>>>(                                 \
             X, W, bias, Y, t.tile_sub_start, t.tile_seg, t.sub_src, t.sub_dst, t.n_dst, t.K, t.tile_rows);         \
     } while (0)
@@ -597,12 +587,7 @@ int conv_forward(const TiledRules &t, const float *X, const float *W, const floa
         }
     }
     if (p.lds_bytes > 160 * 1024) SEI_FAIL("conv: nOut too large for the generic kernel");
-    static bool attr_set = false;
-    if (!attr_set) {
-        SEI_HIP(hipFuncSetAttribute((const void *)conv_tile_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    160 * 1024));
-        attr_set = true;
-    }
+    SEI_TRY(ensure_max_lds((const void *)conv_tile_generic_kernel, 160 * 1024));
     conv_tile_generic_kernel<<<t.n_tiles, 256, p.lds_bytes, st>>>(X, W, bias, Y, t.tile_sub_start, t.tile_seg, t.sub_src,
                                                                  t.sub_dst, t.n_dst, t.K, nIn, nOut, t.tile_rows);
     SEI_LAUNCH_CHECK();

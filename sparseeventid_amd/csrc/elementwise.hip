@@ -137,7 +137,7 @@ static int reduce_launch(int mode, const float *x, const float *y, const float *
     int64_t want = (n + (int64_t)rl * 8 - 1) / ((int64_t)rl * 8);
     int blocks = (int)(want < 1 ? 1 : (want > RED_BLOCKS_MAX ? RED_BLOCKS_MAX : want));
     double *partial;
-    SEI_TRY(pool_alloc_t(&partial, (size_t)blocks * 2 * C));
+    SEI_TRY(pool_alloc_t(&partial, (size_t)blocks * 2 * C, st));
     size_t lds = (size_t)rl * 2 * C * sizeof(double);
 #define RL(MODE, VEC) colreduce_kernel<MODE, VEC><<<blocks, 256, lds, st>>>(x, y, dy, n, C, mean, invstd, leak, partial)
     if (vec == 4) {
@@ -324,7 +324,7 @@ int bn_backward(const float *x, const float *y, const float *dy, int64_t n, int 
         return 0;
     }
     float *coef;
-    SEI_TRY(pool_alloc_t(&coef, 2 * C));
+    SEI_TRY(pool_alloc_t(&coef, 2 * C, st));
     double *partial;
     int blocks;
     SEI_TRY(reduce_launch(1, x, y, dy, n, C, save_mean, save_invstd, leak, &partial, &blocks, st));
@@ -478,7 +478,7 @@ int pool_tanh(const Level *lv, int batch, const float *feats, int C, float *out,
     const double vol = (double)lv->spatial[0] * lv->spatial[1] * lv->spatial[2];
     if (!dout) {
         float *partial;
-        SEI_TRY(pool_alloc_t(&partial, (size_t)batch * POOL_SEGS * C));
+        SEI_TRY(pool_alloc_t(&partial, (size_t)batch * POOL_SEGS * C, st));
         int threads = C < 64 ? 64 : (C > 1024 ? 1024 : (C + 63) / 64 * 64);
         pool_tanh_partial_kernel<<<dim3(batch, POOL_SEGS), threads, 0, st>>>(lv->coords, lv->n, C, feats, partial);
         pool_tanh_final_kernel<<<(batch * C + 255) / 256, 256, 0, st>>>(partial, batch, C, (float)(1.0 / vol), out);

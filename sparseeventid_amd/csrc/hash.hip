@@ -85,7 +85,7 @@ int exclusive_scan_i32(const int32_t *in, int32_t *out, int64_t n, int32_t *tota
     }
     int nb = (int)((n + SCAN_BLOCK - 1) / SCAN_BLOCK);
     int32_t *bs;
-    SEI_TRY(pool_alloc_t(&bs, nb));
+    SEI_TRY(pool_alloc_t(&bs, nb, st));
     scan_reduce_kernel<<<nb, SCAN_THREADS, 0, st>>>(in, n, bs);
     scan_blocksums_kernel<<<1, 1024, 0, st>>>(bs, nb, total_dev);
     scan_apply_kernel<<<nb, SCAN_THREADS, 0, st>>>(in, out, n, bs);
@@ -155,8 +155,8 @@ static uint64_t table_capacity(int64_t n) {
 
 int alloc_table(HashTable *ht, int64_t n, hipStream_t st) {
     uint64_t cap = table_capacity(n);
-    SEI_TRY(pool_alloc_t(&ht->keys, cap));
-    SEI_TRY(pool_alloc_t(&ht->vals, cap));
+    SEI_TRY(pool_alloc_t(&ht->keys, cap, st));
+    SEI_TRY(pool_alloc_t(&ht->vals, cap, st));
     ht->mask = cap - 1;
     SEI_HIP(hipMemsetAsync(ht->keys, 0xFF, cap * sizeof(uint64_t), st));
     SEI_HIP(hipMemsetAsync(ht->vals, 0xFF, cap * sizeof(uint32_t), st));
@@ -178,18 +178,18 @@ int build_input_level(sei_metadata *m, const int32_t *coords, int64_t n, const i
     if (n == 0) {
         lv->n = 0;
         SEI_TRY(alloc_table(&lv->ht, 0, st));
-        SEI_TRY(pool_alloc_t(&lv->coords, 4));
+        SEI_TRY(pool_alloc_t(&lv->coords, 4, st));
         *n_rows = 0;
         return 0;
     }
     SEI_TRY(alloc_table(&lv->ht, n, st));
     uint32_t *slot_of, *new_vals;
     int32_t *flag, *err_total;
-    SEI_TRY(pool_alloc_t(&slot_of, n));
-    SEI_TRY(pool_alloc_t(&flag, n));
-    SEI_TRY(pool_alloc_t(&err_total, 4));  // [0] first out-of-range point, [1] row count, [2] table-full flag
-    SEI_TRY(pool_alloc_t(&new_vals, lv->ht.mask + 1));
-    SEI_TRY(pool_alloc_t(&m->input_row, n));
+    SEI_TRY(pool_alloc_t(&slot_of, n, st));
+    SEI_TRY(pool_alloc_t(&flag, n, st));
+    SEI_TRY(pool_alloc_t(&err_total, 4, st));  // [0] first out-of-range point, [1] row count, [2] table-full flag
+    SEI_TRY(pool_alloc_t(&new_vals, lv->ht.mask + 1, st));
+    SEI_TRY(pool_alloc_t(&m->input_row, n, st));
     SEI_HIP(hipMemsetAsync(err_total, 0xFF, 4 * sizeof(int32_t), st));
     SEI_HIP(hipMemsetAsync(new_vals, 0xFF, (lv->ht.mask + 1) * sizeof(uint32_t), st));
     const int T = 256;
@@ -213,10 +213,10 @@ int build_input_level(sei_metadata *m, const int32_t *coords, int64_t n, const i
     }
     int64_t nr = host[1];
     lv->n = nr;
-    SEI_TRY(pool_alloc_t(&lv->coords, 4 * nr));
-    SEI_TRY(pool_alloc_t(&m->row_first, nr));
-    SEI_TRY(pool_alloc_t(&m->row_last, nr));
-    SEI_TRY(pool_alloc_t(&m->row_count, nr));
+    SEI_TRY(pool_alloc_t(&lv->coords, 4 * nr, st));
+    SEI_TRY(pool_alloc_t(&m->row_first, nr, st));
+    SEI_TRY(pool_alloc_t(&m->row_last, nr, st));
+    SEI_TRY(pool_alloc_t(&m->row_count, nr, st));
     SEI_HIP(hipMemsetAsync(m->row_last, 0xFF, nr * sizeof(int32_t), st));
     SEI_HIP(hipMemsetAsync(m->row_count, 0, nr * sizeof(int32_t), st));
     assign_rows_kernel<<<nb, T, 0, st>>>(coords, slot_of, lv->ht.vals, flag, n, lv->coords, new_vals, m->row_first);
@@ -342,8 +342,8 @@ int larcv_compact(const float *in, int B, int P, int M, int D, int32_t *coords, 
     if (tot >= (1ll << 31) - 64) SEI_FAIL("larcv_compact: batch too large");
     if (tot == 0) { *n_out = 0; return 0; }
     int32_t *flag, *total;
-    SEI_TRY(pool_alloc_t(&flag, tot));
-    SEI_TRY(pool_alloc_t(&total, 2));
+    SEI_TRY(pool_alloc_t(&flag, tot, st));
+    SEI_TRY(pool_alloc_t(&total, 2, st));
     unsigned nb = (unsigned)((tot + 255) / 256);
     int pm = D == 2 ? 1 : 0;
     larcv_flag_kernel<<<nb, 256, 0, st>>>(in, B, P, M, D, pm, flag);

@@ -111,12 +111,12 @@ static int build_tiled(const int32_t *dst_coords, int64_t n_dst, int64_t n_src, 
     t.n_dst = n_dst; t.n_src = n_src; t.K = K; t.tile_rows = tile_rows;
     t.n_tiles = (int)((n_dst + tile_rows - 1) / tile_rows);
     int nt1 = t.n_tiles > 0 ? t.n_tiles : 1;
-    SEI_TRY(pool_alloc_t(&t.tile_sub_start, nt1 + 1));
-    SEI_TRY(pool_alloc_t(&t.tile_seg, (int64_t)(K + 1) * nt1));
-    SEI_TRY(pool_alloc_t(&t.seg_start, (int64_t)(K + 1) * nt1));
+    SEI_TRY(pool_alloc_t(&t.tile_sub_start, nt1 + 1, st));
+    SEI_TRY(pool_alloc_t(&t.tile_seg, (int64_t)(K + 1) * nt1, st));
+    SEI_TRY(pool_alloc_t(&t.seg_start, (int64_t)(K + 1) * nt1, st));
     if (n_dst == 0) {
         SEI_HIP(hipMemsetAsync(t.tile_sub_start, 0, 2 * sizeof(int32_t), st));
-        SEI_TRY(pool_alloc_t(&t.sub_src, 16)); SEI_TRY(pool_alloc_t(&t.sub_dst, 16));
+        SEI_TRY(pool_alloc_t(&t.sub_src, 16, st)); SEI_TRY(pool_alloc_t(&t.sub_dst, 16, st));
         t.built = true;
         *out = t;
         return 0;
@@ -126,9 +126,9 @@ static int build_tiled(const int32_t *dst_coords, int64_t n_dst, int64_t n_src, 
     int32_t *nbr, *tile_subs;
     unsigned long long *totals;
     int64_t tot = (int64_t)t.n_tiles * K * tile_rows;
-    SEI_TRY(pool_alloc_t(&nbr, tot));
-    SEI_TRY(pool_alloc_t(&tile_subs, t.n_tiles + 1));
-    SEI_TRY(pool_alloc_t(&totals, 4));
+    SEI_TRY(pool_alloc_t(&nbr, tot, st));
+    SEI_TRY(pool_alloc_t(&tile_subs, t.n_tiles + 1, st));
+    SEI_TRY(pool_alloc_t(&totals, 4, st));
     SEI_HIP(hipMemsetAsync(totals, 0, 4 * sizeof(unsigned long long), st));
     probe_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, st>>>(dst_coords, n_dst, K, tile_rows, t.n_tiles, g,
                                                                src_ht.keys, src_ht.vals, src_ht.mask, nbr);
@@ -143,8 +143,8 @@ static int build_tiled(const int32_t *dst_coords, int64_t n_dst, int64_t n_src, 
     t.n_rules = (int64_t)host[0];
     t.n_sub = (int64_t)(uint32_t)host[2];
     int64_t ns = t.n_sub > 0 ? t.n_sub : 1;
-    SEI_TRY(pool_alloc_t(&t.sub_src, ns * SUB_SLOTS));
-    SEI_TRY(pool_alloc_t(&t.sub_dst, ns * SUB_SLOTS));
+    SEI_TRY(pool_alloc_t(&t.sub_src, ns * SUB_SLOTS, st));
+    SEI_TRY(pool_alloc_t(&t.sub_dst, ns * SUB_SLOTS, st));
     tile_rules_kernel<true><<<t.n_tiles, tile_rows, 0, st>>>(nbr, K, tile_rows, t.n_tiles, nullptr, nullptr, nullptr,
                                                              nullptr, t.tile_sub_start, t.sub_src, t.sub_dst);
     SEI_LAUNCH_CHECK();
@@ -278,15 +278,15 @@ int build_strided_level(sei_metadata *m, Level *lin, const int32_t size[3], cons
     SEI_TRY(alloc_table(&lo->ht, cand, st));
     if (n == 0) {
         lo->n = 0;
-        SEI_TRY(pool_alloc_t(&lo->coords, 4));
+        SEI_TRY(pool_alloc_t(&lo->coords, 4, st));
     } else {
         uint32_t *slot_of, *new_vals;
         int32_t *flag, *total;
-        SEI_TRY(pool_alloc_t(&slot_of, cand));
-        SEI_TRY(pool_alloc_t(&flag, cand));
-        SEI_TRY(pool_alloc_t(&total, 2));  // [0] number of output sites, [1] table-full flag
+        SEI_TRY(pool_alloc_t(&slot_of, cand, st));
+        SEI_TRY(pool_alloc_t(&flag, cand, st));
+        SEI_TRY(pool_alloc_t(&total, 2, st));  // [0] number of output sites, [1] table-full flag
         SEI_HIP(hipMemsetAsync(total, 0, 2 * sizeof(int32_t), st));
-        SEI_TRY(pool_alloc_t(&new_vals, lo->ht.mask + 1));
+        SEI_TRY(pool_alloc_t(&new_vals, lo->ht.mask + 1, st));
         SEI_HIP(hipMemsetAsync(new_vals, 0xFF, (lo->ht.mask + 1) * sizeof(uint32_t), st));
         unsigned nb = (unsigned)((cand + 255) / 256);
         out_insert_kernel<<<nb, 256, 0, st>>>(lin->coords, n, mult, m1, m2, g, osz[0], osz[1], osz[2], lo->ht.keys,
@@ -300,7 +300,7 @@ int build_strided_level(sei_metadata *m, Level *lin, const int32_t size[3], cons
         if (host2[1]) SEI_FAIL("Convolution: hash table full");
         const int32_t host = host2[0];
         lo->n = host;
-        SEI_TRY(pool_alloc_t(&lo->coords, 4 * (int64_t)(host > 0 ? host : 1)));
+        SEI_TRY(pool_alloc_t(&lo->coords, 4 * (int64_t)(host > 0 ? host : 1), st));
         out_assign_kernel<<<nb, 256, 0, st>>>(lin->coords, n, mult, m1, m2, g, osz[0], osz[1], osz[2], slot_of,
                                               lo->ht.vals, flag, lo->coords, new_vals);
         SEI_LAUNCH_CHECK();
@@ -350,7 +350,7 @@ __global__ void export_fill_kernel(const int32_t *tile_sub_start, const int32_t 
 
 int export_rules(const TiledRules &t, int64_t *start_host, int32_t *rin, int32_t *rout, hipStream_t st) {
     unsigned long long *per_k;
-    SEI_TRY(pool_alloc_t(&per_k, 2 * (t.K + 1)));
+    SEI_TRY(pool_alloc_t(&per_k, 2 * (t.K + 1), st));
     SEI_HIP(hipMemsetAsync(per_k, 0, 2 * (t.K + 1) * sizeof(unsigned long long), st));
     int64_t tot = (int64_t)t.K * t.n_tiles;
     if (t.n_sub > 0)

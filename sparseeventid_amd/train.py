@@ -99,6 +99,16 @@ class Trainer:
         lab = {k: torch.as_tensor(v).to(self.device) for k, v in labels.items()}
         return (c, f, bs), lab
 
+    def stage_larcv(self, larcv_batch, labels):
+        """Device-side input transform (src/io/data_transforms.py:21-49,198-253 on the GPU): the larcv
+        fp32 block [B,P,M,D+1] crosses PCIe as it is and is compacted / cast / keyed by ``sei_larcv_to_scn`` --
+        no float64 host round trip, 16 B per voxel over the link instead of 40."""
+        from . import scn
+        x = larcv_batch if isinstance(larcv_batch, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(larcv_batch, dtype=np.float32))
+        c, f, bs = scn.larcv_to_scn_device(x.to(self.device, non_blocking=True))
+        lab = {k: torch.as_tensor(v).to(self.device, non_blocking=True) for k, v in labels.items()}
+        return (c, f, bs), lab
+
     def forward(self, image):
         if self.fused_head:
             return self.head.forward_pooled(self.encoder.forward_pooled(image))
