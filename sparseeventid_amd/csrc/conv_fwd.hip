@@ -44,15 +44,15 @@ __device__ inline void lds_add(float *p, float v) {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// unconditional load (clamped row) + select: conditional loads make hipcc serialise them with vmcnt(0)
+// Unconditional load of a clamped row and NO select on the loaded value: a padding slot (src < 0) reads row 0 and
+// its products are garbage, but an MFMA output row depends on its own A row only and padding slots are never written
+// back (the read-modify-write below is masked by the rule count of the sub-chunk).
 __device__ inline float4 load_a(const float *__restrict__ X, int src, int CIN, int off) {
-    int row = src >= 0 ? src : 0;
+    int row = src > 0 ? src : 0;
 #ifdef SEI_ABLATE_GATHER  // diagnostic: every gather hits the caches (results are wrong, timing only)
     row &= 1023;
 #endif
-    float4 v = *reinterpret_cast<const float4 *>(X + (size_t)row * CIN + off);
-    if (src < 0) v = make_float4(0.f, 0.f, 0.f, 0.f);
-    return v;
+    return *reinterpret_cast<const float4 *>(X + (size_t)row * CIN + off);
 }
 
 // B operands of one input plane for the wave's NT column tiles.  The weight columns of every column
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256, occ_for(MAXS, NT, SLJ)) void conv_tile_mfma_ke
         for (int m = 0; m < MAXS; m++)
 #pragma unroll
             for (int jj = 0; jj < SLJ; jj++) {
-                a_c[m][jj] = load_a(X, ic.row(m), CIN, 16 * jj + 4 * g);
+                a_c[m][jj] = (m == 0 || m < ic.ms) ? load_a(X, ic.row(m), CIN, 16 * jj + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
                 a_n[m][jj] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         int phase = 0;
@@ -267,11 +267,16 @@ __global__ __launch_bounds__(256, occ_for(MAXS, NT, SLJ)) void conv_tile_mfma_ke
                 stage_slice<PIECES>(W + ((size_t)(same_k ? k : kw) * CIN + (size_t)(same_k ? s + 1 : 0) * SL) * COUT,
                                     wbuf + (size_t)((phase + 1) & 1) * SL * COUT, wave, lane);
                 const int aoff = (same_k ? (s + 1) * SL : 0) + 4 * g;
+                // only the sub-chunks the wave owns in that phase are gathered (wave-uniform branch): a gather of an
+                // absent sub-chunk costs the CU's vector-memory path as much as a real one
+                const int msn = same_k ? ic.ms : in1.ms;
 #pragma unroll
                 for (int m = 0; m < MAXS; m++)
+                    if (m == 0 || m < msn) {
 #pragma unroll
-                    for (int jj = 0; jj < SLJ; jj++)
-                        a_n[m][jj] = load_a(X, same_k ? ic.row(m) : in1.row(m), CIN, aoff + 16 * jj);
+                        for (int jj = 0; jj < SLJ; jj++)
+                            a_n[m][jj] = load_a(X, same_k ? ic.row(m) : in1.row(m), CIN, aoff + 16 * jj);
+                    }
                 const float *wb = wbuf + (size_t)(phase & 1) * SL * COUT + col0;
                 STAMP(2);
                 if (MAXS == 1) {

@@ -171,10 +171,13 @@ __device__ __forceinline__ void wslice(const float4 (&a)[G], const float (&b)[4]
 // operands of slice j (input planes 16j .. 16j+15) of offset k for the G sub-chunks with src rows `rows`
 template <int NT, int G>
 __device__ __forceinline__ void wprefetch(const float *__restrict__ X, const float *__restrict__ wl, int ldy, int CIN,
-                                          int k, int j, const int (&rows)[G], int g, int r16, float4 (&a)[G],
+                                          int k, int j, const int (&rows)[G], int cnt, int g, int r16, float4 (&a)[G],
                                           float (&b)[4][NT]) {
+    // only the sub-chunks that exist are gathered (wave-uniform branches): every vector-memory instruction costs the
+    // CU's address path ~1 KiB of its ~20-30 B/clk, used or not
 #pragma unroll
-    for (int m = 0; m < G; m++) a[m] = wload_a(X, rows[m], CIN, 16 * j + 4 * g);
+    for (int m = 0; m < G; m++)
+        if (m == 0 || m < cnt) a[m] = wload_a(X, rows[m], CIN, 16 * j + 4 * g);
     const float *wn = (SEI_WAVE_ABL & 2) ? wl : wl + ((size_t)k * CIN + 16 * j) * ldy;
 #pragma unroll
     for (int e = 0; e < 4; e++) wload_b<NT>(wn + (size_t)e * ldy, r16, b[e]);
@@ -187,7 +190,7 @@ __device__ __forceinline__ void wprefetch(const float *__restrict__ X, const flo
 // ONCE outside (a branch inside the slice loop made hipcc copy all accumulators every slice).
 template <int NT, int G, int MS>
 __device__ __forceinline__ void wgroup(const float *__restrict__ X, const float *__restrict__ wl, int ldy, int CIN, int NS,
-                                       int kc, int kn, const int (&rc)[G], const int (&rn)[G], const uint32_t (&d4)[G],
+                                       int kc, int kn, const int (&rc)[G], const int (&rn)[G], int cn, const uint32_t (&d4)[G],
                                        const int (&src)[G], float *acc_tile, int g, int r16, float4 (&a0)[G],
                                        float (&b0)[4][NT], WStamp &st) {
     constexpr int NC = 16 * NT;
@@ -200,7 +203,7 @@ __device__ __forceinline__ void wgroup(const float *__restrict__ X, const float 
         for (int n = 0; n < NT; n++) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     int j = 0;
     for (; j + 2 <= NS; j += 2) {
-        wprefetch<NT, G>(X, wl, ldy, CIN, kc, j + 1, rc, g, r16, a1, b1);
+        wprefetch<NT, G>(X, wl, ldy, CIN, kc, j + 1, rc, MS, g, r16, a1, b1);
         // the loads above are ISSUED before this slice's MFMAs (hipcc otherwise sinks them behind the MFMAs)
         __builtin_amdgcn_sched_barrier(0);
         WSTAMP(1);
@@ -210,7 +213,7 @@ __device__ __forceinline__ void wgroup(const float *__restrict__ X, const float 
         int rr[G];
 #pragma unroll
         for (int m = 0; m < G; m++) rr[m] = same ? rc[m] : rn[m];
-        wprefetch<NT, G>(X, wl, ldy, CIN, same ? kc : kn, same ? j + 2 : 0, rr, g, r16, a0, b0);
+        wprefetch<NT, G>(X, wl, ldy, CIN, same ? kc : kn, same ? j + 2 : 0, rr, same ? MS : cn, g, r16, a0, b0);
         __builtin_amdgcn_sched_barrier(0);
         WSTAMP(1);
         wslice<NT, G, MS>(a1, b1, acc);
@@ -218,7 +221,7 @@ __device__ __forceinline__ void wgroup(const float *__restrict__ X, const float 
         WSTAMP_ADD(8, 2 * 4 * MS * NT);
     }
     if (j < NS) {  // odd slice count: the next group's slice 0 lands in the second set and is moved over
-        wprefetch<NT, G>(X, wl, ldy, CIN, kn, 0, rn, g, r16, a1, b1);
+        wprefetch<NT, G>(X, wl, ldy, CIN, kn, 0, rn, cn, g, r16, a1, b1);
         __builtin_amdgcn_sched_barrier(0);
         WSTAMP(1);
         wslice<NT, G, MS>(a0, b0, acc);
@@ -337,7 +340,7 @@ __global__ __launch_bounds__(64, wave_occ(NT, G)) void conv_wave_mfma_kernel(
             int r0[G];
 #pragma unroll
             for (int m = 0; m < G; m++) r0[m] = ix0.row(m);
-            wprefetch<NT, G>(X, wl, ldy, CIN, it0.k, 0, r0, g, r16, a0, b0);
+            wprefetch<NT, G>(X, wl, ldy, CIN, it0.k, 0, r0, ix0.cnt, g, r16, a0, b0);
         }
         __syncthreads();  // single-wave workgroup: orders the tile initialisation before the first read-modify-write
         WSTAMP(0);
@@ -350,7 +353,7 @@ __global__ __launch_bounds__(64, wave_occ(NT, G)) void conv_wave_mfma_kernel(
                 rc[m] = ix0.row(m);
                 rn[m] = ix1.row(m);
             }
-#define WGROUP(MS_) wgroup<NT, G, (MS_ <= G ? MS_ : 1)>(X, wl, ldy, CIN, NS, it0.k, kn, rc, rn, ix0.d4, ix0.src, acc_tile, g, r16, a0, b0, st)
+#define WGROUP(MS_) wgroup<NT, G, (MS_ <= G ? MS_ : 1)>(X, wl, ldy, CIN, NS, it0.k, kn, rc, rn, ix1.cnt, ix0.d4, ix0.src, acc_tile, g, r16, a0, b0, st)
             if (G == 1 || ix0.cnt == 1) WGROUP(1);
             else if (G == 2 || ix0.cnt == 2) WGROUP(2);
             else if (G == 3 || ix0.cnt == 3) WGROUP(3);
