@@ -44,15 +44,20 @@ __device__ inline void lds_add(float *p, float v) {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// Unconditional load of a clamped row and NO select on the loaded value: a padding slot (src < 0) reads row 0 and
-// its products are garbage, but an MFMA output row depends on its own A row only and padding slots are never written
-// back (the read-modify-write below is masked by the rule count of the sub-chunk).
+// unconditional load (clamped row) + select: conditional loads make hipcc serialise them with vmcnt(0)
 __device__ inline float4 load_a(const float *__restrict__ X, int src, int CIN, int off) {
     int row = src > 0 ? src : 0;
 #ifdef SEI_ABLATE_GATHER  // diagnostic: every gather hits the caches (results are wrong, timing only)
     row &= 1023;
 #endif
-    return *reinterpret_cast<const float4 *>(X + (size_t)row * CIN + off);
+    float4 v = *reinterpret_cast<const float4 *>(X + (size_t)row * CIN + off);
+#ifndef SEI_TILE_NOSELECT
+    // Padding slots feed ZEROS to the MFMA.  Their output rows are never written back, so garbage would be equally
+    // correct -- but measured on one device (tools/tile_ab.sh, levels 1-3) zeros run 5-7 % faster than row-0 data
+    // (51.7 / 66.1 / 71.8 vs 49.2 / 61.9 / 68.5 TFLOP/s): the chip holds a higher clock on the ~10 % all-zero rows.
+    if (src < 0) v = make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
+    return v;
 }
 
 // B operands of one input plane for the wave's NT column tiles.  The weight columns of every column
@@ -226,7 +231,7 @@ __global__ __launch_bounds__(256, occ_for(MAXS, NT, SLJ)) void conv_tile_mfma_ke
         for (int m = 0; m < MAXS; m++)
 #pragma unroll
             for (int jj = 0; jj < SLJ; jj++) {
-                a_c[m][jj] = (m == 0 || m < ic.ms) ? load_a(X, ic.row(m), CIN, 16 * jj + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+                a_c[m][jj] = load_a(X, ic.row(m), CIN, 16 * jj + 4 * g);
                 a_n[m][jj] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         int phase = 0;
@@ -267,9 +272,11 @@ __global__ __launch_bounds__(256, occ_for(MAXS, NT, SLJ)) void conv_tile_mfma_ke
                 stage_slice<PIECES>(W + ((size_t)(same_k ? k : kw) * CIN + (size_t)(same_k ? s + 1 : 0) * SL) * COUT,
                                     wbuf + (size_t)((phase + 1) & 1) * SL * COUT, wave, lane);
                 const int aoff = (same_k ? (s + 1) * SL : 0) + 4 * g;
-                // only the sub-chunks the wave owns in that phase are gathered (wave-uniform branch): a gather of an
-                // absent sub-chunk costs the CU's vector-memory path as much as a real one
+#ifdef SEI_TILE_SKIP  // experiment: gather only the sub-chunks the wave owns in that phase
                 const int msn = same_k ? ic.ms : in1.ms;
+#else
+                const int msn = MAXS;
+#endif
 #pragma unroll
                 for (int m = 0; m < MAXS; m++)
                     if (m == 0 || m < msn) {

@@ -150,12 +150,18 @@ struct WaveIdx {
 
 // one slice (16 input planes = 4 MFMA steps) for MS sub-chunks sharing the B operands
 template <int NT, int G, int MS>
-__device__ __forceinline__ void wslice(const float4 (&a)[G], const float (&b)[4][NT], f32x4 (&acc)[MS][NT]) {
+__device__ __forceinline__ void wslice(const float4 (&a)[G], const float (&b)[4][NT], const int (&rows)[G],
+                                       f32x4 (&acc)[MS][NT]) {
 #pragma unroll
     for (int e = 0; e < 4; e++) {
 #pragma unroll
         for (int m = 0; m < MS; m++) {
-            const float av = e == 0 ? a[m].x : e == 1 ? a[m].y : e == 2 ? a[m].z : a[m].w;
+            float av = e == 0 ? a[m].x : e == 1 ? a[m].y : e == 2 ? a[m].z : a[m].w;
+#ifndef SEI_WAVE_NOZERO
+            // padding slots feed zeros (applied HERE, a slice after the gather was issued -- a select at the load would
+            // wait for it): correctness does not need it, the chip clocks higher on all-zero rows (see conv_fwd.hip)
+            av = rows[m] >= 0 ? av : 0.f;
+#endif
 #pragma unroll
             for (int n = 0; n < NT; n++) {
                 if (SEI_WAVE_ABL & 8) {
@@ -207,7 +213,7 @@ __device__ __forceinline__ void wgroup(const float *__restrict__ X, const float 
         // the loads above are ISSUED before this slice's MFMAs (hipcc otherwise sinks them behind the MFMAs)
         __builtin_amdgcn_sched_barrier(0);
         WSTAMP(1);
-        wslice<NT, G, MS>(a0, b0, acc);
+        wslice<NT, G, MS>(a0, b0, rc, acc);
         WSTAMP(2);
         const bool same = j + 2 < NS;  // else: slice 0 of the next group
         int rr[G];
@@ -216,7 +222,7 @@ __device__ __forceinline__ void wgroup(const float *__restrict__ X, const float 
         wprefetch<NT, G>(X, wl, ldy, CIN, same ? kc : kn, same ? j + 2 : 0, rr, same ? MS : cn, g, r16, a0, b0);
         __builtin_amdgcn_sched_barrier(0);
         WSTAMP(1);
-        wslice<NT, G, MS>(a1, b1, acc);
+        wslice<NT, G, MS>(a1, b1, rc, acc);
         WSTAMP(2);
         WSTAMP_ADD(8, 2 * 4 * MS * NT);
     }
@@ -224,7 +230,7 @@ __device__ __forceinline__ void wgroup(const float *__restrict__ X, const float 
         wprefetch<NT, G>(X, wl, ldy, CIN, kn, 0, rn, cn, g, r16, a1, b1);
         __builtin_amdgcn_sched_barrier(0);
         WSTAMP(1);
-        wslice<NT, G, MS>(a0, b0, acc);
+        wslice<NT, G, MS>(a0, b0, rc, acc);
         WSTAMP(2);
         WSTAMP_ADD(8, 4 * MS * NT);
 #pragma unroll
