@@ -16,7 +16,6 @@
 #include "common.h"
 
 #include <stdlib.h>
-#include <string.h>
 
 namespace sei {
 
@@ -273,140 +272,6 @@ __global__ __launch_bounds__(256) void conv_dw_mfma_kernel(
     for (int idx = threadIdx.x; idx < MT * 16 * COUT; idx += 256) out[idx] = red[idx];
 }
 
-// ------------------------------------------------------------------------------------------ dW, operands shared through LDS
-// One workgroup per (k, split) computes the WHOLE nIn x nOut block of dW[k]: the 16 src rows of X and the 16 dst rows
-// of dY of a sub-chunk are fetched ONCE per workgroup by LDS-DMA (global_load_lds_dwordx4, per-lane source address =
-// row gather, linear LDS image) and read back by all four waves, each of which owns one quadrant of the block
-// (wave (wi, wj): MT x NT tiles of 16 x 16).  Against the register-operand kernel above (every wave gathers its own
-// A and B fragments: (MT+NT)/(MT*NT) x 64 B per MFMA through the vector-memory path, 170 B at 96 planes) this moves
-// ~85-100 B per MFMA; that path (~20-30 B/clk per CU, and its time ADDS to the MFMA time in these kernels) is what
-// bounds both kernels (profiles/r02_conv_wave_diag_L2_C96.txt).  No cross-wave reduction: a wave's accumulators are
-// final for its quadrant.  Padding slots read X from a zero row, so no select sits between the LDS reads and the MFMAs.
-template <int MT, int NT, int SPS>
-struct DwLds {
-    static constexpr int CIN = 32 * MT, COUT = 32 * NT;
-    static constexpr int XS = CIN + 16, YS = COUT + 16;  // row strides (floats), = 16 mod 32: conflict-free b32 column reads
-    static constexpr int SUB_FLOATS = 16 * (XS + YS);    // LDS image of one sub-chunk: X rows, then dY rows
-    static constexpr int STAGE_FLOATS = SPS * SUB_FLOATS;
-    static constexpr int PIECES = (STAGE_FLOATS * 4 + 1023) / 1024;  // 1-KiB DMA pieces per stage
-    static constexpr int IDX = SPS * 16;                 // rule slots per stage
-    static constexpr size_t lds_bytes() { return (size_t)(2 * PIECES * 256 + 2 * 3 * IDX) * 4; }
-};
-
-template <int MT, int NT, int SPS>
-__global__ __launch_bounds__(256) void conv_dw_lds_kernel(
-    const float *__restrict__ X, const float *__restrict__ dY, const int32_t *__restrict__ tile_sub_start,
-    const int32_t *__restrict__ seg_start, const int32_t *__restrict__ sub_src, const uint8_t *__restrict__ sub_dst,
-    int n_tiles, int TR, int tiles_per_split, int S, int K, const float *__restrict__ zero_row, float *__restrict__ slab) {
-    typedef DwLds<MT, NT, SPS> L;
-    extern __shared__ __attribute__((aligned(16))) float lds_f[];
-    __shared__ int list_sub[DW_LIST_CAP];
-    __shared__ int list_tile[DW_LIST_CAP];
-    __shared__ int scan_tmp[8];
-    float *stage = lds_f;                                            // [2][PIECES*256]
-    int *idx_src = reinterpret_cast<int *>(lds_f + 2 * L::PIECES * 256);  // [3][IDX]
-    int *idx_dst = idx_src + 3 * L::IDX;                             // [3][IDX]
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int k = j % K, s = (j / K) * 8 + xcd;
-    if (s >= S) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r16 = lane & 15, g = lane >> 4;
-    const int wi = wave >> 1, wj = wave & 1;
-    f32x4 acc[MT][NT];
-#pragma unroll
-    for (int m = 0; m < MT; m++)
-#pragma unroll
-        for (int n = 0; n < NT; n++) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const int t_begin = s * tiles_per_split;
-    const int t_end = min(n_tiles, t_begin + tiles_per_split);
-    for (int tb = t_begin; tb < t_end; tb += DW_TILES_PER_ITER) {
-        const int total = dw_build_list(tile_sub_start, seg_start, n_tiles, k, tb, t_end, list_sub, list_tile, scan_tmp);
-        const int n_stages = (total + SPS - 1) / SPS;
-        // rule indices of a stage -> idx ring (threads 0 .. IDX-1; padding items / slots read as src -1, dst row 0)
-        auto load_idx = [&](int st) {
-            if (threadIdx.x < L::IDX) {
-                const int it = st * SPS + (int)threadIdx.x / 16, r = threadIdx.x & 15;
-                int sv = -1, dv = 0;
-                if (st < n_stages && it < total) {
-                    const int64_t c = list_sub[it];
-                    sv = sub_src[c * SUB_SLOTS + r];
-                    dv = list_tile[it] * TR + sub_dst[c * SUB_SLOTS + r];
-                }
-                idx_src[(st % 3) * L::IDX + threadIdx.x] = sv;
-                idx_dst[(st % 3) * L::IDX + threadIdx.x] = sv >= 0 ? dv : 0;
-            }
-        };
-        // LDS-DMA of a stage's X / dY rows: piece p, lane l writes bytes [1024 p + 16 l, +16) of the linear image
-        auto issue_dma = [&](int st) {
-            const int *is = idx_src + (st % 3) * L::IDX, *id = idx_dst + (st % 3) * L::IDX;
-            float *dst = stage + (size_t)(st & 1) * L::PIECES * 256;
-#pragma unroll
-            for (int q = 0; q < (L::PIECES + 3) / 4; q++) {
-                const int piece = q * 4 + wave;
-                if (piece < L::PIECES) {  // wave-uniform
-                    const int f = piece * 256 + lane * 4;          // float offset in the stage image
-                    const int sc = f / L::SUB_FLOATS, o = f - sc * L::SUB_FLOATS;
-                    const float *src = zero_row;
-                    if (sc < SPS) {
-                        if (o < 16 * L::XS) {
-                            const int rule = o / L::XS, fo = o - rule * L::XS;
-                            const int row = is[sc * 16 + rule];
-                            if (fo < L::CIN) src = row >= 0 ? X + (size_t)row * L::CIN + fo : zero_row + fo;
-                        } else {
-                            const int o2 = o - 16 * L::XS;
-                            const int rule = o2 / L::YS, fo = o2 - rule * L::YS;
-                            const int row = id[sc * 16 + rule];
-                            if (fo < L::COUT) src = dY + (size_t)row * L::COUT + fo;
-                        }
-                    }
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                                     (__attribute__((address_space(3))) void *)(dst + piece * 256), 16, 0, 0);
-                }
-            }
-        };
-        if (n_stages > 0) {
-            load_idx(0);
-            load_idx(1);
-            __syncthreads();
-            issue_dma(0);
-            for (int st = 0; st < n_stages; st++) {
-                load_idx(st + 2);
-                __syncthreads();  // stage st has landed (the barrier waits vmcnt(0)); buffer (st+1)&1 and idx slot st+2 are free
-                if (st + 1 < n_stages) issue_dma(st + 1);
-                const float *img = stage + (size_t)(st & 1) * L::PIECES * 256;
-#pragma unroll
-                for (int sc = 0; sc < SPS; sc++) {
-                    const float *xi = img + sc * L::SUB_FLOATS + wi * (16 * MT) + r16;
-                    const float *yi = img + sc * L::SUB_FLOATS + 16 * L::XS + wj * (16 * NT) + r16;
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        float a[MT], b[NT];
-#pragma unroll
-                        for (int m = 0; m < MT; m++) a[m] = xi[(4 * q + g) * L::XS + 16 * m];
-#pragma unroll
-                        for (int n = 0; n < NT; n++) b[n] = yi[(4 * q + g) * L::YS + 16 * n];
-#pragma unroll
-                        for (int m = 0; m < MT; m++)
-#pragma unroll
-                            for (int n = 0; n < NT; n++) acc[m][n] = mfma16(a[m], b[n], acc[m][n]);
-                    }
-                }
-            }
-        }
-        __syncthreads();
-    }
-    // this wave's quadrant of dW[k] (split s): D[row 4g+i][col r16] of tile (m, n)
-    float *out = slab + (size_t)(k * S + s) * L::CIN * L::COUT;
-#pragma unroll
-    for (int m = 0; m < MT; m++)
-#pragma unroll
-        for (int n = 0; n < NT; n++)
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-                out[(size_t)(wi * 16 * MT + 16 * m + 4 * g + i) * L::COUT + wj * 16 * NT + 16 * n + r16] = acc[m][n][i];
-}
-
 // dW for tiny nIn (stem: nIn = 1): HBM-bound gather of dY rows; lane = output plane, the 64/COUT lane groups
 // take different rule slots; all loads of a sub-chunk are issued together; fixed-order reductions.
 template <int CIN, int COUT>
@@ -519,34 +384,6 @@ static int launch_dw(const TiledRules &t, const float *X, const float *dY, int n
     return 0;
 }
 
-template <int MT, int NT, int SPS>
-static int launch_dw_lds(const TiledRules &t, const float *X, const float *dY, int tps, int S, const float *zero_row,
-                         float *slab, hipStream_t st) {
-    typedef DwLds<MT, NT, SPS> L;
-    SEI_TRY(ensure_max_lds((const void *)conv_dw_lds_kernel<MT, NT, SPS>, 128 * 1024));
-    dim3 grid(8 * t.K * ((S + 7) / 8), 1, 1);
-    conv_dw_lds_kernel<MT, NT, SPS><<<grid, 256, L::lds_bytes(), st>>>(X, dY, t.tile_sub_start, t.seg_start, t.sub_src,
-                                                                      t.sub_dst, t.n_tiles, t.tile_rows, tps, S, t.K,
-                                                                      zero_row, slab);
-    SEI_LAUNCH_CHECK();
-    return 0;
-}
-
-// nIn = 32 MT, nOut = 32 NT (every layer of the reference networks); SPS sub-chunks per barrier
-static int dispatch_dw_lds(int mt, int nt, const TiledRules &t, const float *X, const float *dY, int tps, int S,
-                           const float *zero_row, float *slab, hipStream_t st) {
-    const char *e = getenv("SEI_DW_SPS");
-    const int sps = e ? atoi(e) : (mt + nt <= 8 ? 2 : 1);
-#define DWL(MT_, NT_)                                                                                       \
-    if (mt == MT_ && nt == NT_)                                                                             \
-        return sps == 2 ? launch_dw_lds<MT_, NT_, 2>(t, X, dY, tps, S, zero_row, slab, st)                  \
-                        : launch_dw_lds<MT_, NT_, 1>(t, X, dY, tps, S, zero_row, slab, st);
-    DWL(1, 1) DWL(2, 2) DWL(3, 3) DWL(4, 4) DWL(5, 5) DWL(6, 6)
-    DWL(1, 2) DWL(2, 3) DWL(3, 4) DWL(4, 5) DWL(5, 6) DWL(6, 4)
-#undef DWL
-    return -1;  // no instantiation: the caller falls back to the register-operand kernel
-}
-
 #define DW_CASE(MT_, NT_) \
     if (mt == MT_ && nt == NT_) return launch_dw<MT_, NT_>(t, X, dY, nIn, nOut, tps, S, slab, st);
 
@@ -611,20 +448,7 @@ int conv_backward_weight(const TiledRules &t, const float *X, const float *dY, f
     SEI_TRY(pool_alloc_t(&slab, (size_t)t.K * S * per, st));
     int rc = 0;
     dim3 grid(t.K, S, 1);
-    bool done = false;
-    const char *dwk = getenv("SEI_DW_KERNEL");
-    if (mfma_ok && nIn % 32 == 0 && nOut % 32 == 0 && !(dwk && !strcmp(dwk, "reg"))) {
-        // operands shared through LDS (one workgroup per (k, split) owns the whole nIn x nOut block)
-        float *zero_row;
-        SEI_TRY(pool_alloc_t(&zero_row, 1024, st));
-        SEI_HIP(hipMemsetAsync(zero_row, 0, 1024 * sizeof(float), st));
-        rc = dispatch_dw_lds(nIn / 32, nOut / 32, t, X, dY, tps, S, zero_row, slab, st);
-        pool_free(zero_row);
-        if (rc >= 0) done = true;
-        else rc = 0;
-    }
-    if (done) {
-    } else if (mfma_ok)
+    if (mfma_ok)
         rc = dispatch_dw(mt, nt, t, X, dY, nIn, nOut, tps, S, slab, st);
     else if (small) {
 #define SM(CIN_, COUT_) conv_dw_smallcin_kernel<CIN_, COUT_><<<grid, 256, 0, st>>>(                              \

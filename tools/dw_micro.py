@@ -13,7 +13,7 @@ def main():
     ap.add_argument("--events", type=int, default=16)
     ap.add_argument("--levels", type=int, nargs="*", default=[0, 1, 2, 3, 4, 5])
     ap.add_argument("--iters", type=int, default=10)
-    ap.add_argument("--variants", nargs="*", default=["reg", "lds:2", "lds:1"])
+    ap.add_argument("--variants", nargs="*", default=["reg"], help="SEI_DW_KERNEL[:SEI_DW_SPS] values (only read by experiment builds)")
     a = ap.parse_args()
     from bench import generate_batch
     arr, _ = generate_batch(0, 0, a.events, (900, 900, 900), 50000, "tracks", min(16, os.cpu_count() or 8))
