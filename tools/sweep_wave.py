@@ -9,8 +9,8 @@ import numpy as np
 
 CH = {0: 32, 1: 64, 2: 96, 3: 128, 4: 160, 5: 192}
 PLANS = {
-    32: ["tile", "2,64,2", "2,128,2", "2,128,4", "2,256,4", "1,128,4"],
-    64: ["tile", "4,64,2", "4,128,2", "4,128,4", "2,128,4", "4,64,3"],
+    32: ["tile", "2,64,2", "2,128,2", "2,128,3", "2,128,4", "2,192,2", "2,192,3", "2,256,4", "1,128,4"],
+    64: ["tile", "4,64,2", "4,64,3", "4,64,4", "4,128,4", "2,128,4", "2,128,3"],
     96: ["tile", "6,64,2", "6,64,3", "3,128,4", "3,64,2", "6,128,2"],
     128: ["tile", "8,64,2", "4,64,2", "4,128,4", "4,128,2", "8,64,3"],
     160: ["tile", "5,64,2", "5,128,2", "5,64,3"],
