@@ -225,26 +225,40 @@ def main():
             tot_ms = tot_fl = tot_n = 0.0
             kinds = {}
             for kind, name in ((0, "conv_fwd"), (1, "conv_bwd_input"), (2, "conv_bwd_weight"), (3, "rulebook_build"),
-                               (4, "batchnorm")):
+                               (4, "batchnorm"), (6, "conv_fwd_32planes"), (7, "conv_bwd_input_32planes")):
                 lib.sei_prof_query(kind, q)
                 kinds[name] = {"launches": q[0], "ms": q[1], "gflop": q[2] / 1e9, "gbyte": q[3] / 1e9}
-                if kind in (0, 1):
+                if kind in (0, 1, 6, 7):
                     tot_n += q[0]; tot_ms += q[1]; tot_fl += q[2]
+            # the 32 -> 32 plane layers (level 0) are counted in the dominant-kernel totals AND priced on their own against
+            # the HBM roofline (8 flop per algorithmic byte): algorithmic bytes / HIP-event time
+            c32 = {"launches": kinds["conv_fwd_32planes"]["launches"] + kinds["conv_bwd_input_32planes"]["launches"],
+                   "ms": kinds["conv_fwd_32planes"]["ms"] + kinds["conv_bwd_input_32planes"]["ms"],
+                   "gbyte": kinds["conv_fwd_32planes"]["gbyte"] + kinds["conv_bwd_input_32planes"]["gbyte"]}
+            for k2 in ("conv_fwd", "conv_bwd_input"):     # the headline per-kind entries keep meaning "all forward / dX launches"
+                for f2 in ("launches", "ms", "gflop", "gbyte"):
+                    kinds[k2][f2] += kinds[k2 + "_32planes"][f2]
             if tot_ms > 0:
                 ach = tot_fl / (tot_ms * 1e-3) / 1e12
                 # HBM traffic cannot be read live: it comes from the committed PMC passes of this same command
                 traffic = None
-                tpath = os.path.join(ROOT, "profiles", "r01_conv_fwd_hbm_traffic.json")
+                tpath = os.path.join(ROOT, "profiles", "r02_conv_fwd_hbm_traffic.json")
                 if (os.path.exists(tpath) and args.model == "dune3d" and args.mode == "train" and args.batch == 64
                         and args.voxels == 50000 and args.kind == "tracks"):
                     traffic = json.load(open(tpath))["traffic_bytes_per_launch"]
-                roof = {"bound": "mfma", "kernel": "conv_tile_mfma_kernel (fwd + dX launches)", "achieved": ach,
-                        "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3, "traffic": traffic,
+                roof = {"bound": "mfma", "kernel": "conv_tile_mfma_kernel + conv_wave_mfma_kernel (all forward + dX launches)",
+                        "achieved": ach, "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3, "traffic": traffic,
                         "traffic_note": "HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
-                                        "(profiles/r01_conv_fwd_hbm_traffic.json); algorithmic bytes per launch %.3g"
+                                        "(profiles/r02_conv_fwd_hbm_traffic.json); algorithmic bytes per launch %.3g"
                                         % ((kinds["conv_fwd"]["gbyte"] + kinds["conv_bwd_input"]["gbyte"]) * 1e9 / max(tot_n, 1)),
                         "launches_per_step": tot_n / args.steps, "avg_launch_ms": tot_ms / max(tot_n, 1),
                         "per_kind_per_step": {k: {kk: vv / args.steps for kk, vv in v.items()} for k, v in kinds.items()}}
+                if c32["ms"] > 0:
+                    roof["hbm_view_32plane_layers"] = {
+                        "bound": "hbm", "kernel": "conv_wave_mfma_kernel<2,2> (32 -> 32 planes, forward + dX launches)",
+                        "achieved": c32["gbyte"] / (c32["ms"] * 1e-3) / 1e3, "peak": 8.0, "unit": "TB/s",
+                        "frac": c32["gbyte"] / (c32["ms"] * 1e-3) / 1e3 / 8.0,
+                        "launches_per_step": c32["launches"] / args.steps, "avg_launch_ms": c32["ms"] / max(c32["launches"], 1)}
         cpu = None
         if world == 1 and args.cpu_events > 0 and args.model == "dune3d":
             cpu = cpu_baseline(arr, labels, image_size, min(args.cpu_events, args.batch), args.mode == "fwd",

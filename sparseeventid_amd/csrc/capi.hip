@@ -380,7 +380,8 @@ int sei_conv_forward(sei_rulebook_t *rb, const float *X, const float *W, const f
             SEI_TRY(aw.stage(W, (size_t)t->K * nIn * nOut, st));
             W = aw.p;
         }
-        ProfScope ps(PROF_CONV_FWD, st, 2.0 * t->n_rules * nIn * nOut, conv_bytes(*t, nIn, nOut));
+        ProfScope ps(nIn == 32 && nOut == 32 ? PROF_CONV_FWD_C32 : PROF_CONV_FWD, st, 2.0 * t->n_rules * nIn * nOut,
+                     conv_bytes(*t, nIn, nOut));
         return conv_forward(*t, X, W, bias, Y, nIn, nOut, st);
     }
     // the workgroup-tile MFMA kernel reads B operands with wide LDS loads from column-permuted weights (tiny copy, <= 4 MB)
@@ -412,7 +413,8 @@ static int conv_backward_input_impl(sei_rulebook_t *rb, const float *dY, const f
     int rc = conv_transform_weights(W, Wt, t->K, nIn, nOut, true, rb->submanifold, p.kind == 1 ? p.col_group : 0,
                                     p.kind == 1 ? p.blocks : 1, st);
     if (!rc) {
-        ProfScope ps(PROF_CONV_BWD_IN, st, 2.0 * t->n_rules * nIn * nOut, conv_bytes(*t, nOut, nIn));
+        ProfScope ps(nIn == 32 && nOut == 32 ? PROF_CONV_BWD_IN_C32 : PROF_CONV_BWD_IN, st, 2.0 * t->n_rules * nIn * nOut,
+                     conv_bytes(*t, nOut, nIn));
         rc = conv_forward(*t, dY, Wt, nullptr, dX, nOut, nIn, st, dX_init);
     }
     pool_free(Wt);

@@ -245,7 +245,10 @@ int pool_tanh(const Level *lv, int batch, const float *feats, int C, float *out,
               hipStream_t st);
 
 // ---- profiling (HIP events around launches) ----
-enum ProfKind { PROF_CONV_FWD = 0, PROF_CONV_BWD_IN = 1, PROF_CONV_BWD_W = 2, PROF_RULES = 3, PROF_BN = 4, PROF_OTHER = 5, PROF_NKIND = 6 };
+// kinds 6 / 7: forward / dX launches of the 32 -> 32 plane layers (level 0 of the DUNE network), kept apart because they
+// are priced against the HBM roofline, not the MFMA one
+enum ProfKind { PROF_CONV_FWD = 0, PROF_CONV_BWD_IN = 1, PROF_CONV_BWD_W = 2, PROF_RULES = 3, PROF_BN = 4, PROF_OTHER = 5,
+                PROF_CONV_FWD_C32 = 6, PROF_CONV_BWD_IN_C32 = 7, PROF_NKIND = 8 };
 struct ProfScope {
     int kind;
     hipStream_t st;
