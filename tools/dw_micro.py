@@ -13,7 +13,8 @@ def main():
     ap.add_argument("--events", type=int, default=16)
     ap.add_argument("--levels", type=int, nargs="*", default=[0, 1, 2, 3, 4, 5])
     ap.add_argument("--iters", type=int, default=10)
-    ap.add_argument("--variants", nargs="*", default=["reg"], help="SEI_DW_KERNEL[:SEI_DW_SPS] values (only read by experiment builds)")
+    ap.add_argument("--variants", nargs="*", default=["default"],
+                    help="each variant = comma list of ENV=VALUE the library reads per call (SEI_DW_MT, SEI_DW_FIT_KB), or 'default'")
     a = ap.parse_args()
     from bench import generate_batch
     arr, _ = generate_batch(0, 0, a.events, (900, 900, 900), 50000, "tracks", min(16, os.cpu_count() or 8))
@@ -40,10 +41,12 @@ def main():
             R = rb.n_rules
             dw = torch.empty(27, C, C, device="cuda"); ref = None
             for v in a.variants:
-                kind, _, sps = v.partition(":")
-                os.environ["SEI_DW_KERNEL"] = kind
-                if sps:
-                    os.environ["SEI_DW_SPS"] = sps
+                for kv in ("SEI_DW_MT", "SEI_DW_FIT_KB"):
+                    os.environ.pop(kv, None)
+                if v != "default":
+                    for kv in v.split(","):
+                        k_, _, val = kv.partition("=")
+                        os.environ[k_] = val
                 fn = lambda: check(lib().sei_conv_backward_weight(rb.h, p(x), p(dy), p(dw), None, C, C, st))
                 fn(); torch.cuda.synchronize()
                 if ref is None:
@@ -55,7 +58,7 @@ def main():
                     fn()
                 ev1.record(); torch.cuda.synchronize()
                 ms = ev0.elapsed_time(ev1) / a.iters
-                print("L%d C=%d N=%d R/N=%.2f dW %-6s %.3f ms  %.1f TFLOP/s  (max diff vs first %.1e)" % (
+                print("L%d C=%d N=%d R/N=%.2f dW %-32s %.3f ms  %.1f TFLOP/s  (max diff vs first %.1e)" % (
                     level, C, n, R / n, v, ms, 2.0 * R * C * C / ms / 1e9, err), flush=True)
         t = scn.Convolution(3, 16, 16, 2, 2, False).cuda()(t)
         level += 1
