@@ -9,15 +9,20 @@ namespace sei {
 // One thread per (tile, k, row-in-tile): nbr[(tile*K + k)*TR + r] = src row feeding dst row
 // tile*TR + r through offset k, or -1.  Consecutive lanes = consecutive dst rows, same offset:
 // coalesced coord reads / nbr writes, and the probed keys are spatial neighbours of each other.
-__global__ void probe_kernel(const int32_t *__restrict__ dst_coords, int64_t n_dst, int K, int TR, int n_tiles,
+// KP = offsets actually probed.  Submanifold rulebooks (mode 0, odd filter) probe only the first half of the
+// offsets plus the centre: a hit (i -> o) at offset k is also the rule (o -> i) at the mirrored offset K-1-k, so
+// it is written to both places (the table is preset to -1) -- half the hash probes, which dominate this kernel
+// (92 % of the stem's 125 probes per site are misses).
+__global__ void probe_kernel(const int32_t *__restrict__ dst_coords, int64_t n_dst, int K, int KP, int TR, int n_tiles,
                              ProbeGeom g, const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals,
                              uint64_t mask, int32_t *__restrict__ nbr) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (int64_t)n_tiles * K * TR) return;
+    if (t >= (int64_t)n_tiles * KP * TR) return;
     int r = (int)(t % TR);
     int64_t tk = t / TR;
-    int k = (int)(tk % K);
-    int64_t row = (tk / K) * TR + r;
+    int k = (int)(tk % KP);
+    const int64_t tile = tk / KP;
+    int64_t row = tile * TR + r;
     int res = -1;
     if (row < n_dst) {
         int4 c = reinterpret_cast<const int4 *>(dst_coords)[row];
@@ -37,7 +42,15 @@ __global__ void probe_kernel(const int32_t *__restrict__ dst_coords, int64_t n_d
         ok = ok && q0 >= 0 && q0 < g.s0 && q1 >= 0 && q1 < g.s1 && q2 >= 0 && q2 < g.s2;
         if (ok) res = hash_find(keys, vals, mask, pack_key(q0, q1, q2, c.w));
     }
-    nbr[t] = res;
+    if (KP == K) {
+        nbr[(tile * K + k) * TR + r] = res;
+    } else if (res >= 0) {
+        nbr[(tile * K + k) * TR + r] = res;
+        if (k != K - 1 - k) {  // mirrored rule: dst row `res` receives from `row` through offset K-1-k
+            const int64_t mt = res / TR;
+            nbr[(mt * K + (K - 1 - k)) * TR + (res - mt * TR)] = (int32_t)row;
+        }
+    }
 }
 
 // One workgroup (TR threads) per tile, thread = dst row.  FILL=false: count sub-chunks per offset and
@@ -130,8 +143,13 @@ static int build_tiled(const int32_t *dst_coords, int64_t n_dst, int64_t n_src, 
     SEI_TRY(pool_alloc_t(&tile_subs, t.n_tiles + 1, st));
     SEI_TRY(pool_alloc_t(&totals, 4, st));
     SEI_HIP(hipMemsetAsync(totals, 0, 4 * sizeof(unsigned long long), st));
-    probe_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, st>>>(dst_coords, n_dst, K, tile_rows, t.n_tiles, g,
-                                                               src_ht.keys, src_ht.vals, src_ht.mask, nbr);
+    // submanifold: dst level == src level and the filter is odd in every dimension, so rules come in mirrored pairs
+    const bool mirror = g.mode == 0 && (g.f0 & 1) && (g.f1 & 1) && (g.f2 & 1) && K > 1;
+    const int KP = mirror ? (K + 1) / 2 : K;
+    if (mirror) SEI_HIP(hipMemsetAsync(nbr, 0xFF, (size_t)tot * sizeof(int32_t), st));
+    const int64_t ptot = (int64_t)t.n_tiles * KP * tile_rows;
+    probe_kernel<<<(unsigned)((ptot + 255) / 256), 256, 0, st>>>(dst_coords, n_dst, K, KP, tile_rows, t.n_tiles, g,
+                                                                src_ht.keys, src_ht.vals, src_ht.mask, nbr);
     tile_rules_kernel<false><<<t.n_tiles, tile_rows, 0, st>>>(nbr, K, tile_rows, t.n_tiles, tile_subs, t.tile_seg,
                                                               t.seg_start, totals, nullptr, nullptr, nullptr);
     SEI_LAUNCH_CHECK();
