@@ -432,9 +432,9 @@ int conv_backward_weight(const TiledRules &t, const float *X, const float *dY, f
     bool small = !mfma_ok && nIn <= 4 && (nOut == 16 || nOut == 32 || nOut == 64);
     // splits: a split's dY / X rows (re-read by the K workgroups of that split, which share an XCD) should fit
     // that XCD's 4 MiB L2; bounded slab size; at least enough workgroups to fill 256 CUs
-    // measured per level (tools/dw_micro.py, profiles/r02_conv_dw_knobs.log): up to 96 planes 1.5 MiB of rows per split is
-    // 3-23 % faster than 3 MiB (more, shorter workgroups); the wider layers prefer 3 MiB
-    int64_t fit_kb = getenv("SEI_DW_FIT_KB") ? atoi(getenv("SEI_DW_FIT_KB")) : (nIn + nOut <= 192 ? 1536 : 3072);
+    // 3 MiB of rows per split; 1.5 MiB measured faster in the 16-event micro-benchmark but slower in the 64-event step
+    // (conv_bwd_weight 101.7 vs 97.4 ms; profiles/r02_conv_dw_knobs.log): tune at the benchmark's size
+    int64_t fit_kb = getenv("SEI_DW_FIT_KB") ? atoi(getenv("SEI_DW_FIT_KB")) : 3072;
     int64_t rows_fit = (fit_kb << 10) / ((int64_t)(nIn + nOut) * 4);
     int tps = (int)(rows_fit / t.tile_rows);
     if (tps > DW_TILES_PER_ITER) tps = DW_TILES_PER_ITER;
