@@ -116,6 +116,15 @@ int sei_bn_forward(const float *x, int64_t n, int32_t C, const float *gamma, con
                    float *running_mean, float *running_var, float eps, float momentum, int32_t training,
                    float leak, const float *residual, float *y, float *save_mean, float *save_invstd,
                    sei_stream_t stream);
+/* Fused scn.SubmanifoldConvolution / scn.Convolution -> scn.BatchNormalization (+LeakyReLU, +AddTable residual)
+ * forward (Block.forward / ConvolutionDownsample.forward, sparse_building_blocks.py:47-57,130-139): same results as
+ * sei_conv_forward followed by sei_bn_forward, but in training mode the per-channel sums of the convolution output
+ * are accumulated in the convolution kernel's epilogue (fixed order), so BatchNorm does not re-read it for its
+ * statistics.  Yconv [n_out,nOut] (kept for the backward) and Ybn [n_out,nOut] are both written. */
+int sei_conv_bn_forward(sei_rulebook_t *rb, const float *X, const float *W, const float *bias, float *Yconv,
+                        int32_t nIn, int32_t nOut, const float *gamma, const float *beta, float *running_mean,
+                        float *running_var, float eps, float momentum, int32_t training, float leak,
+                        const float *residual, float *Ybn, float *save_mean, float *save_invstd, sei_stream_t stream);
 /* backward of the above (training statistics): needs x, y (for the activation sign), dy.
  * dx [n,C]; dresidual [n,C] or NULL; dgamma/dbeta [C] or NULL. */
 int sei_bn_backward(const float *x, const float *y, const float *dy, int64_t n, int32_t C,

@@ -362,37 +362,65 @@ struct AlignedArg {
     ~AlignedArg() { pool_free(tmp); }
 };
 
-int sei_conv_forward(sei_rulebook_t *rb, const float *X, const float *W, const float *bias, float *Y, int32_t nIn,
-                     int32_t nOut, sei_stream_t stream) {
+// forward convolution; stats_out / parts_out (optional): BatchNorm partial sums of Y from the kernel epilogue
+static int conv_forward_impl(sei_rulebook_t *rb, const float *X, const float *W, const float *bias, float *Y, int32_t nIn,
+                             int32_t nOut, hipStream_t st, double **stats_out, int64_t *parts_out) {
     if (!rb) SEI_FAIL("null rulebook");
-    hipStream_t st = (hipStream_t)stream;
     const TiledRules *t;
     const int64_t n_dst = rb->lout ? rb->lout->n : 0;
     const ConvPlan p = plan_conv(nIn, nOut, rulebook_K(rb), n_dst);
     SEI_TRY(get_tiled(rb, false, p.tile_rows, &t, st));
+    double *stats = nullptr;
+    if (stats_out) {
+        const int64_t parts = conv_stats_parts(p, *t);
+        if (parts > 0) SEI_TRY(pool_alloc_t(&stats, (size_t)parts * 2 * nOut, st));
+        *stats_out = stats;
+        *parts_out = parts;
+    }
     AlignedArg ab, aw;
     if (p.kind != 0) {
         SEI_TRY(ab.stage(bias, nOut, st));
         bias = ab.p;
     }
+    const int kind = nIn == 32 && nOut == 32 ? PROF_CONV_FWD_C32 : PROF_CONV_FWD;
     if (p.kind != 1) {  // natural weight layout: no copy
         if (p.kind == 2) {
             SEI_TRY(aw.stage(W, (size_t)t->K * nIn * nOut, st));
             W = aw.p;
         }
-        ProfScope ps(nIn == 32 && nOut == 32 ? PROF_CONV_FWD_C32 : PROF_CONV_FWD, st, 2.0 * t->n_rules * nIn * nOut,
-                     conv_bytes(*t, nIn, nOut));
-        return conv_forward(*t, X, W, bias, Y, nIn, nOut, st);
+        ProfScope ps(kind, st, 2.0 * t->n_rules * nIn * nOut, conv_bytes(*t, nIn, nOut));
+        return conv_forward(*t, X, W, bias, Y, nIn, nOut, st, nullptr, stats);
     }
     // the workgroup-tile MFMA kernel reads B operands with wide LDS loads from column-permuted weights (tiny copy, <= 4 MB)
     float *Wp;
     SEI_TRY(pool_alloc_t(&Wp, (size_t)t->K * nIn * nOut, st));
     int rc = conv_transform_weights(W, Wp, t->K, nIn, nOut, false, false, p.col_group, p.blocks, st);
     if (!rc) {
-        ProfScope ps(PROF_CONV_FWD, st, 2.0 * t->n_rules * nIn * nOut, conv_bytes(*t, nIn, nOut));
-        rc = conv_forward(*t, X, Wp, bias, Y, nIn, nOut, st);
+        ProfScope ps(kind, st, 2.0 * t->n_rules * nIn * nOut, conv_bytes(*t, nIn, nOut));
+        rc = conv_forward(*t, X, Wp, bias, Y, nIn, nOut, st, nullptr, stats);
     }
     pool_free(Wp);
+    return rc;
+}
+
+int sei_conv_forward(sei_rulebook_t *rb, const float *X, const float *W, const float *bias, float *Y, int32_t nIn,
+                     int32_t nOut, sei_stream_t stream) {
+    return conv_forward_impl(rb, X, W, bias, Y, nIn, nOut, (hipStream_t)stream, nullptr, nullptr);
+}
+
+int sei_conv_bn_forward(sei_rulebook_t *rb, const float *X, const float *W, const float *bias, float *Yconv, int32_t nIn,
+                        int32_t nOut, const float *gamma, const float *beta, float *running_mean, float *running_var,
+                        float eps, float momentum, int32_t training, float leak, const float *residual, float *Ybn,
+                        float *save_mean, float *save_invstd, sei_stream_t stream) {
+    if (!rb) SEI_FAIL("null rulebook");
+    hipStream_t st = (hipStream_t)stream;
+    double *stats = nullptr;
+    int64_t parts = 0;
+    int rc = conv_forward_impl(rb, X, W, bias, Yconv, nIn, nOut, st, training ? &stats : nullptr, &parts);
+    if (!rc)
+        rc = bn_forward(Yconv, rb->lout ? rb->lout->n : 0, nOut, gamma, beta, running_mean, running_var, eps, momentum,
+                        training, leak, residual, Ybn, save_mean, save_invstd, st, stats, parts);
+    pool_free(stats);
     return rc;
 }
 

@@ -218,10 +218,14 @@ struct ConvPlan {
 };
 ConvPlan plan_conv(int nIn, int nOut, int K, int64_t n_dst);
 bool plan_wave(int nIn, int nOut, int K, int64_t n_dst, ConvPlan *p);
+// stats (optional, MFMA kernels only): per-(tile, part) column sums of the OUTPUT rows, [n_parts][2][nOut] doubles
+// (sum, sum of squares) accumulated in the kernel epilogue from the LDS tile -- BatchNorm statistics without a second
+// read of the conv output.  conv_stats_parts() = how many parts this plan writes (0: the plan cannot).
 int conv_forward(const TiledRules &t, const float *X, const float *W, const float *bias, float *Y, int nIn, int nOut,
-                 hipStream_t st, const float *init = nullptr);
+                 hipStream_t st, const float *init = nullptr, double *stats = nullptr);
 int conv_forward_wave(const TiledRules &t, const ConvPlan &p, const float *X, const float *W, const float *bias, float *Y,
-                      int nIn, int nOut, const float *init, hipStream_t st);
+                      int nIn, int nOut, const float *init, double *stats, hipStream_t st);
+int64_t conv_stats_parts(const ConvPlan &p, const TiledRules &t);
 // Wout[k][r][perm(c)]: transpose=false: rows=nIn, cols=nOut (forward); transpose=true: Wout[k][co][perm(ci)] = W[ks][ci][co]
 // with ks = flip ? K-1-k : k (dX).  perm = column permutation inside groups of `col_group` columns (0 = identity).
 int conv_transform_weights(const float *W, float *Wout, int K, int nIn, int nOut, bool transpose, bool flip, int col_group, int blocks,
@@ -230,9 +234,10 @@ int conv_backward_weight(const TiledRules &t, const float *X, const float *dY, f
                          hipStream_t st);
 // elementwise.hip
 int colsum(const float *x, int64_t n, int C, float *out, hipStream_t st);
+// stats / n_parts: precomputed partial sums of x (conv epilogue) -- training mode then skips its own reduction pass
 int bn_forward(const float *x, int64_t n, int C, const float *gamma, const float *beta, float *rmean, float *rvar,
                float eps, float momentum, int training, float leak, const float *residual, float *y, float *save_mean,
-               float *save_invstd, hipStream_t st);
+               float *save_invstd, hipStream_t st, const double *stats = nullptr, int64_t n_parts = 0);
 int bn_backward(const float *x, const float *y, const float *dy, int64_t n, int C, const float *gamma,
                 const float *save_mean, const float *save_invstd, float leak, int training, float *dx, float *dres,
                 float *dgamma, float *dbeta, hipStream_t st);

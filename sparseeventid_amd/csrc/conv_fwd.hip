@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256, occ_for(MAXS, NT, SLJ)) void conv_tile_mfma_ke
     const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ Y,
     const int32_t *__restrict__ tile_sub_start, const int32_t *__restrict__ tile_seg,
     const int32_t *__restrict__ sub_src, const uint8_t *__restrict__ sub_dst, int64_t n_dst, int K, int CIN, int n_tiles,
-    const float *__restrict__ init, int ldy, int blocks) {
+    const float *__restrict__ init, int ldy, int blocks, double *__restrict__ stats) {
     extern __shared__ float lds[];
     constexpr int U = 4 / CS;  // units (groups of CS waves) dealing sub-chunks
     constexpr int TR = 16 * MAXS * U;
@@ -353,6 +353,26 @@ __global__ __launch_bounds__(256, occ_for(MAXS, NT, SLJ)) void conv_tile_mfma_ke
             *reinterpret_cast<float4 *>(Y + (size_t)(row0 + r) * ldy + ycol0 + 4 * v) =
                 *reinterpret_cast<const float4 *>(acc_tile + (size_t)r * ASTRIDE + 4 * v);
     }
+    if (stats) {
+        // BatchNorm statistics of the output while the tile is still in LDS: column sums over the tile's valid rows
+        // in fp64, PARTS row-interleaved partial sums per tile (fixed order: bit-identical reruns); the BN forward only
+        // finalizes them (no second read of Y).  Layout [tile * PARTS + part][2][ldy].
+        constexpr int PARTS = 256 / COUT > 0 ? 256 / COUT : 1;
+        const int64_t left = n_dst - row0;
+        const int rows = left < TR ? (int)left : TR;
+        for (int e = threadIdx.x; e < PARTS * COUT; e += 256) {
+            const int part = e / COUT, c = e - part * COUT;
+            double s0 = 0.0, s1 = 0.0;
+            for (int r = part; r < rows; r += PARTS) {
+                const double v = (double)acc_tile[(size_t)r * ASTRIDE + c];
+                s0 += v;
+                s1 += v * v;
+            }
+            double *o = stats + ((size_t)tile * PARTS + part) * 2 * ldy + ycol0 + c;
+            o[0] = s0;
+            o[ldy] = s1;
+        }
+    }
     STAMP(11);
     STAMP_ADD(7, 1);
     STAMP_FLUSH;
@@ -536,22 +556,35 @@ ConvPlan plan_conv(int nIn, int nOut, int K, int64_t n_dst) {
 
 template <int NT, int CS, int SLJ, int MAXS>
 static int launch_mfma(const TiledRules &t, const ConvPlan &p, const float *X, const float *W, const float *bias,
-                       float *Y, int nIn, const float *init, hipStream_t st) {
+                       float *Y, int nIn, const float *init, double *stats, hipStream_t st) {
     SEI_TRY(ensure_max_lds((const void *)conv_tile_mfma_kernel<NT, CS, SLJ, MAXS>, 160 * 1024));
     conv_tile_mfma_kernel<NT, CS, SLJ, MAXS><<<((t.n_tiles * p.blocks + 7) / 8) * 8, 256, p.lds_bytes, st>>>(
         X, W, bias, Y, t.tile_sub_start, t.tile_seg, t.sub_src, t.sub_dst, t.n_dst, t.K, nIn, t.n_tiles, init,
-        NT * CS * 16 * p.blocks, p.blocks);
+        NT * CS * 16 * p.blocks, p.blocks, stats);
     SEI_LAUNCH_CHECK();
     return 0;
 }
 
 #define FWD_CASE(NT_, CS_, SLJ_, MAXS_)                                            \
     if (p.nt == NT_ && p.cs == CS_ && p.slj == SLJ_ && p.maxs == MAXS_)            \
-        return launch_mfma<NT_, CS_, SLJ_, MAXS_>(t, p, X, W, bias, Y, nIn, init, st);
+        return launch_mfma<NT_, CS_, SLJ_, MAXS_>(t, p, X, W, bias, Y, nIn, init, stats, st);
 #define FWD_BOTH_SLJ(NT_, CS_, MAXS_) FWD_CASE(NT_, CS_, 1, MAXS_) FWD_CASE(NT_, CS_, 2, MAXS_)
 
+int64_t conv_stats_parts(const ConvPlan &p, const TiledRules &t) {
+    if (t.n_dst == 0 || t.n_sub == 0) return 0;
+    if (p.kind == 1) {
+        const int cout = p.nt * p.cs * 16;
+        return (int64_t)t.n_tiles * (256 / cout > 0 ? 256 / cout : 1);
+    }
+    if (p.kind == 2) {
+        const int nc = p.nt * 16;
+        return (int64_t)t.n_tiles * (64 / nc > 0 ? 64 / nc : 1);
+    }
+    return 0;
+}
+
 int conv_forward(const TiledRules &t, const float *X, const float *W, const float *bias, float *Y, int nIn, int nOut,
-                 hipStream_t st, const float *init) {
+                 hipStream_t st, const float *init, double *stats) {
     if (t.n_dst == 0) return 0;
     if (init && bias) SEI_FAIL("conv_forward: bias and init are mutually exclusive");
     if (t.n_sub == 0 && !init) {
@@ -563,7 +596,8 @@ int conv_forward(const TiledRules &t, const float *X, const float *W, const floa
     ConvPlan p = plan_conv(nIn, nOut, t.K, t.n_dst);
     if (init && (p.kind == 0 || t.n_sub == 0)) SEI_FAIL("conv_forward: init is only supported by the MFMA kernels");
     if (p.tile_rows != t.tile_rows) SEI_FAIL("conv_forward: rulebook tile size does not match the kernel plan");
-    if (p.kind == 2) return conv_forward_wave(t, p, X, W, bias, Y, nIn, nOut, init, st);
+    if (stats && (p.kind == 0 || t.n_sub == 0)) SEI_FAIL("conv_forward: statistics are only produced by the MFMA kernels");
+    if (p.kind == 2) return conv_forward_wave(t, p, X, W, bias, Y, nIn, nOut, init, stats, st);
     if (p.kind == 1) {
         // default plans
         FWD_BOTH_SLJ(1, 1, 2) FWD_BOTH_SLJ(2, 1, 2) FWD_BOTH_SLJ(3, 1, 2) FWD_BOTH_SLJ(4, 1, 2) FWD_BOTH_SLJ(5, 1, 2)

@@ -267,7 +267,7 @@ __global__ __launch_bounds__(64, wave_occ(NT, G)) void conv_wave_mfma_kernel(
     const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ Y,
     const int32_t *__restrict__ tile_sub_start, const int32_t *__restrict__ tile_seg,
     const int32_t *__restrict__ sub_src, const uint8_t *__restrict__ sub_dst, int64_t n_dst, int K, int CIN, int n_tiles,
-    const float *__restrict__ init, int ldy, int blocks, int TR) {
+    const float *__restrict__ init, int ldy, int blocks, int TR, double *__restrict__ stats) {
     extern __shared__ float lds[];
     constexpr int NC = 16 * NT;  // columns of this wave = LDS row stride
     // workgroups (= waves) are dealt round-robin to the 8 XCDs: give every XCD one contiguous run of tiles so that
@@ -380,6 +380,24 @@ __global__ __launch_bounds__(64, wave_occ(NT, G)) void conv_wave_mfma_kernel(
             *reinterpret_cast<float4 *>(Y + (size_t)(row0 + r) * ldy + col0 + 4 * v) =
                 *reinterpret_cast<const float4 *>(acc_tile + (size_t)r * NC + 4 * v);
     }
+    if (stats) {
+        // BatchNorm statistics of the output from the LDS tile (see conv_fwd.hip): [tile * PARTS + part][2][ldy] doubles
+        constexpr int PARTS = 64 / NC > 0 ? 64 / NC : 1;
+        const int64_t left = n_dst - row0;
+        const int rows = left < TR ? (int)left : TR;
+        for (int e = lane; e < PARTS * NC; e += 64) {
+            const int part = e / NC, c = e - part * NC;
+            double s0 = 0.0, s1 = 0.0;
+            for (int r = part; r < rows; r += PARTS) {
+                const double v = (double)acc_tile[(size_t)r * NC + c];
+                s0 += v;
+                s1 += v * v;
+            }
+            double *o = stats + ((size_t)tile * PARTS + part) * 2 * ldy + col0 + c;
+            o[0] = s0;
+            o[ldy] = s1;
+        }
+    }
     WSTAMP(5);
     WSTAMP_ADD(7, 1);
     st.flush();
@@ -435,20 +453,20 @@ bool plan_wave(int nIn, int nOut, int K, int64_t n_dst, ConvPlan *p) {
 
 template <int NT, int G>
 static int launch_wave(const TiledRules &t, const ConvPlan &p, const float *X, const float *W, const float *bias, float *Y,
-                       int nIn, int nOut, const float *init, hipStream_t st) {
+                       int nIn, int nOut, const float *init, double *stats, hipStream_t st) {
     const int nwork = t.n_tiles * p.blocks;
     conv_wave_mfma_kernel<NT, G><<<((nwork + 7) / 8) * 8, 64, p.lds_bytes, st>>>(
         X, W, bias, Y, t.tile_sub_start, t.tile_seg, t.sub_src, t.sub_dst, t.n_dst, t.K, nIn, t.n_tiles, init, nOut,
-        p.blocks, t.tile_rows);
+        p.blocks, t.tile_rows, stats);
     SEI_LAUNCH_CHECK();
     return 0;
 }
 
 #define WAVE_CASE(NT_, G_) \
-    if (p.nt == NT_ && p.g == G_) return launch_wave<NT_, G_>(t, p, X, W, bias, Y, nIn, nOut, init, st);
+    if (p.nt == NT_ && p.g == G_) return launch_wave<NT_, G_>(t, p, X, W, bias, Y, nIn, nOut, init, stats, st);
 
 int conv_forward_wave(const TiledRules &t, const ConvPlan &p, const float *X, const float *W, const float *bias, float *Y,
-                      int nIn, int nOut, const float *init, hipStream_t st) {
+                      int nIn, int nOut, const float *init, double *stats, hipStream_t st) {
     WAVE_CASE(1, 2) WAVE_CASE(2, 2) WAVE_CASE(3, 2) WAVE_CASE(4, 2) WAVE_CASE(5, 2) WAVE_CASE(6, 2) WAVE_CASE(7, 2) WAVE_CASE(8, 2)
     WAVE_CASE(1, 3) WAVE_CASE(2, 3) WAVE_CASE(3, 3) WAVE_CASE(4, 3) WAVE_CASE(5, 3) WAVE_CASE(6, 3) WAVE_CASE(7, 3) WAVE_CASE(8, 3)
     WAVE_CASE(1, 4) WAVE_CASE(2, 4) WAVE_CASE(3, 4) WAVE_CASE(4, 4) WAVE_CASE(5, 4) WAVE_CASE(6, 4)

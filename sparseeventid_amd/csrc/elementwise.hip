@@ -286,17 +286,24 @@ static inline unsigned bn_blocks(int64_t total_vec, int C, int vec) {
 
 int bn_forward(const float *x, int64_t n, int C, const float *gamma, const float *beta, float *rmean, float *rvar,
                float eps, float momentum, int training, float leak, const float *residual, float *y, float *save_mean,
-               float *save_invstd, hipStream_t st) {
-    ProfScope ps(PROF_BN, st, 0.0, (residual ? 16.0 : 12.0) * (double)n * C);
+               float *save_invstd, hipStream_t st, const double *stats, int64_t n_parts) {
+    ProfScope ps(PROF_BN, st, 0.0, ((residual ? 16.0 : 12.0) - (training && stats ? 4.0 : 0.0)) * (double)n * C);
     if (training) {
         if (n == 0) return 0;
-        double *partial;
-        int blocks;
-        SEI_TRY(reduce_launch(0, x, nullptr, nullptr, n, C, nullptr, nullptr, 1.f, &partial, &blocks, st));
-        finalize_kernel<<<C, 64, 0, st>>>(partial, blocks, C, n, 0, eps, momentum, save_mean, save_invstd,
-                                                      rmean, rvar);
-        SEI_LAUNCH_CHECK();
-        pool_free(partial);
+        if (stats) {
+            // per-tile partial sums written by the convolution's epilogue: only the (fixed-order) finalize is left
+            if (n_parts > 0x7fffffff) SEI_FAIL("bn_forward: too many partial sums");
+            finalize_kernel<<<C, 64, 0, st>>>(stats, (int)n_parts, C, n, 0, eps, momentum, save_mean, save_invstd, rmean, rvar);
+            SEI_LAUNCH_CHECK();
+        } else {
+            double *partial;
+            int blocks;
+            SEI_TRY(reduce_launch(0, x, nullptr, nullptr, n, C, nullptr, nullptr, 1.f, &partial, &blocks, st));
+            finalize_kernel<<<C, 64, 0, st>>>(partial, blocks, C, n, 0, eps, momentum, save_mean, save_invstd,
+                                                          rmean, rvar);
+            SEI_LAUNCH_CHECK();
+            pool_free(partial);
+        }
     } else {
         if (!rmean || !rvar) SEI_FAIL("BatchNormalization eval mode needs running statistics");
         eval_stats_kernel<<<(C + 63) / 64, 64, 0, st>>>(rmean, rvar, eps, C, save_mean, save_invstd);

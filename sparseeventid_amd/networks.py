@@ -39,14 +39,12 @@ class Block(nn.Module):
         self.activation = activation()
 
     def forward(self, x, residual=None):
-        out = self.conv1(x)
         leak = self.activation.leak if isinstance(self.activation, scn.LeakyReLU) else None
-        if self._do_normalization and (leak is not None or isinstance(self.activation, scn.Identity)):
-            # fused BN (+residual) + activation; Identity activation -> leak 1
-            fused = scn.SparseConvNetTensor(metadata=out.metadata, spatial_size=out.spatial_size)
-            fused.features = self.norm.forward_features(out.features, leak=1.0 if leak is None else leak,
-                                                        residual=None)
-            return fused
+        if (self._do_normalization and (leak is not None or isinstance(self.activation, scn.Identity))
+                and x.features.is_cuda):
+            # conv -> BN + activation as one node (Identity activation -> leak 1); BN statistics from the conv epilogue
+            return scn.conv_bn_act(x, self.conv1, self.norm, 1.0 if leak is None else leak)
+        out = self.conv1(x)
         if self._do_normalization:
             out = self.norm(out)
         return self.activation(out)
@@ -73,12 +71,9 @@ class ResidualBlock(nn.Module):
             return scn.residual_block(x, c1.conv1, c1.norm, c2.conv1, c2.norm, c1.activation.leak, self.relu.leak)
         residual = self.residual(x)
         out = self.convolution_1(x)
-        if c2._do_normalization:
+        if c2._do_normalization and x.features.is_cuda:
             # conv -> [BN + residual add + LeakyReLU] fused: one read of each operand, one write
-            y = c2.conv1(out)
-            fused = scn.SparseConvNetTensor(metadata=y.metadata, spatial_size=y.spatial_size)
-            fused.features = c2.norm.forward_features(y.features, leak=self.relu.leak, residual=residual.features)
-            return fused
+            return scn.conv_bn_act(out, c2.conv1, c2.norm, self.relu.leak, residual=residual.features)
         out = c2(out)
         out = self.add([out, residual])
         return self.relu(out)
@@ -101,11 +96,11 @@ class ConvolutionDownsample(nn.Module):
         self.relu = scn.LeakyReLU()
 
     def forward(self, x):
+        if self._do_normalization and x.features.is_cuda:
+            return scn.conv_bn_act(x, self.conv, self.norm, self.relu.leak)
         out = self.conv(x)
         if self._do_normalization:
-            fused = scn.SparseConvNetTensor(metadata=out.metadata, spatial_size=out.spatial_size)
-            fused.features = self.norm.forward_features(out.features, leak=self.relu.leak)
-            return fused
+            return self.relu(self.norm(out))
         return self.relu(out)
 
 

@@ -275,24 +275,24 @@ class _ResidualBlock(torch.autograd.Function):
     [N,C] add, and five autograd nodes become one."""
 
     @staticmethod
-    def forward(ctx, x, rb, w1, b1, g1, be1, rm1, rv1, w2, b2, g2, be2, rm2, rv2, eps, momentum, training, leak1, leak2):
+    def forward(ctx, x, rb, w1, b1, g1, be1, rm1, rv1, w2, b2, g2, be2, rm2, rv2, bn1cfg, bn2cfg, leak1, leak2):
+        (eps1, mom1, training1), (eps2, mom2, training2) = bn1cfg, bn2cfg
         n, C = x.shape
         dev = x.device
         L = lib()
         st = _stream()
-        y1 = torch.empty_like(x)
-        check(L.sei_conv_forward(rb.h, _ptr(x), _ptr(w1), _ptr(b1), _ptr(y1), C, C, st))
-        a1 = torch.empty_like(x)
+        # conv -> BN(+act) pairs through the fused entry point: the BN statistics come out of the conv epilogue
+        y1, a1 = torch.empty_like(x), torch.empty_like(x)
         m1, s1 = torch.empty(C, device=dev), torch.empty(C, device=dev)
-        check(L.sei_bn_forward(_ptr(y1), n, C, _ptr(g1), _ptr(be1), _ptr(rm1), _ptr(rv1), eps, momentum,
-                               1 if training else 0, leak1, None, _ptr(a1), _ptr(m1), _ptr(s1), st))
-        y2 = torch.empty_like(x)
-        check(L.sei_conv_forward(rb.h, _ptr(a1), _ptr(w2), _ptr(b2), _ptr(y2), C, C, st))
-        out = torch.empty_like(x)
+        check(L.sei_conv_bn_forward(rb.h, _ptr(x), _ptr(w1), _ptr(b1), _ptr(y1), C, C, _ptr(g1), _ptr(be1), _ptr(rm1),
+                                    _ptr(rv1), eps1, mom1, 1 if training1 else 0, leak1, None, _ptr(a1), _ptr(m1),
+                                    _ptr(s1), st))
+        y2, out = torch.empty_like(x), torch.empty_like(x)
         m2, s2 = torch.empty(C, device=dev), torch.empty(C, device=dev)
-        check(L.sei_bn_forward(_ptr(y2), n, C, _ptr(g2), _ptr(be2), _ptr(rm2), _ptr(rv2), eps, momentum,
-                               1 if training else 0, leak2, _ptr(x), _ptr(out), _ptr(m2), _ptr(s2), st))
-        ctx.rb, ctx.training, ctx.leak1, ctx.leak2 = rb, training, leak1, leak2
+        check(L.sei_conv_bn_forward(rb.h, _ptr(a1), _ptr(w2), _ptr(b2), _ptr(y2), C, C, _ptr(g2), _ptr(be2), _ptr(rm2),
+                                    _ptr(rv2), eps2, mom2, 1 if training2 else 0, leak2, _ptr(x), _ptr(out), _ptr(m2),
+                                    _ptr(s2), st))
+        ctx.rb, ctx.training1, ctx.training2, ctx.leak1, ctx.leak2 = rb, training1, training2, leak1, leak2
         ctx.has_b1, ctx.has_b2 = b1 is not None, b2 is not None
         ctx.save_for_backward(x, y1, a1, y2, out, w1, w2, g1, g2, m1, s1, m2, s2)
         return out
@@ -306,11 +306,11 @@ class _ResidualBlock(torch.autograd.Function):
         L = lib()
         st = _stream()
         rb = ctx.rb
-        tr = 1 if ctx.training else 0
+        tr1, tr2 = (1 if ctx.training1 else 0), (1 if ctx.training2 else 0)
         vec = lambda: torch.empty(C, dtype=torch.float32, device=dev)
         # BN2 (+ skip + act) backward: dy2, and the skip branch's gradient dres
         dy2, dres, dg2, dbe2 = torch.empty_like(x), torch.empty_like(x), vec(), vec()
-        check(L.sei_bn_backward(_ptr(y2), _ptr(out), _ptr(dout), n, C, _ptr(g2), _ptr(m2), _ptr(s2), ctx.leak2, tr,
+        check(L.sei_bn_backward(_ptr(y2), _ptr(out), _ptr(dout), n, C, _ptr(g2), _ptr(m2), _ptr(s2), ctx.leak2, tr2,
                                 _ptr(dy2), _ptr(dres), _ptr(dg2), _ptr(dbe2), st))
         dw2 = torch.empty_like(w2)
         db2 = vec() if ctx.has_b2 else None
@@ -319,7 +319,7 @@ class _ResidualBlock(torch.autograd.Function):
         check(L.sei_conv_backward_input(rb.h, _ptr(dy2), _ptr(w2), _ptr(da1), C, C, st))
         del dy2
         dy1, dg1, dbe1 = torch.empty_like(x), vec(), vec()
-        check(L.sei_bn_backward(_ptr(y1), _ptr(a1), _ptr(da1), n, C, _ptr(g1), _ptr(m1), _ptr(s1), ctx.leak1, tr,
+        check(L.sei_bn_backward(_ptr(y1), _ptr(a1), _ptr(da1), n, C, _ptr(g1), _ptr(m1), _ptr(s1), ctx.leak1, tr1,
                                 _ptr(dy1), None, _ptr(dg1), _ptr(dbe1), st))
         del da1
         dw1 = torch.empty_like(w1)
@@ -330,7 +330,74 @@ class _ResidualBlock(torch.autograd.Function):
             dx = torch.empty_like(x)
             # dX = dres + conv1^T(dy1): the skip gradient seeds the kernel's accumulators
             check(L.sei_conv_backward_input_accumulate(rb.h, _ptr(dy1), _ptr(w1), _ptr(dres), _ptr(dx), C, C, st))
-        return (dx, None, dw1, db1, dg1, dbe1, None, None, dw2, db2, dg2, dbe2, None, None, None, None, None, None, None)
+        return (dx, None, dw1, db1, dg1, dbe1, None, None, dw2, db2, dg2, dbe2, None, None, None, None, None, None)
+
+
+class _ConvBN(torch.autograd.Function):
+    """conv -> BatchNorm (+residual add) + LeakyReLU as ONE autograd node (Block.forward / ConvolutionDownsample.forward,
+    sparse_building_blocks.py:47-57,130-139).  Same kernels as the separate modules; in training mode the BatchNorm
+    statistics are accumulated in the convolution kernel's epilogue (sei_conv_bn_forward) instead of a second read of
+    the convolution output."""
+
+    @staticmethod
+    def forward(ctx, x, rb, w, b, gamma, beta, rmean, rvar, eps, momentum, training, leak, residual):
+        nIn, nOut = w.shape[1], w.shape[2]
+        if x.shape[1] != nIn:
+            raise RuntimeError("convolution: input has %d planes, weight expects %d" % (x.shape[1], nIn))
+        if x.shape[0] != rb.n_src:
+            raise RuntimeError("convolution: %d feature rows but the metadata level has %d" % (x.shape[0], rb.n_src))
+        dev = x.device
+        y = torch.empty((rb.n_dst, nOut), dtype=torch.float32, device=dev)
+        a = torch.empty_like(y)
+        mean, invstd = torch.empty(nOut, device=dev), torch.empty(nOut, device=dev)
+        check(lib().sei_conv_bn_forward(rb.h, _ptr(x), _ptr(w), _ptr(b), _ptr(y), nIn, nOut, _ptr(gamma), _ptr(beta),
+                                        _ptr(rmean), _ptr(rvar), eps, momentum, 1 if training else 0, leak,
+                                        _ptr(residual), _ptr(a), _ptr(mean), _ptr(invstd), _stream()))
+        ctx.rb, ctx.leak, ctx.training = rb, leak, training
+        ctx.has_bias, ctx.has_res, ctx.has_affine = b is not None, residual is not None, gamma is not None
+        ctx.save_for_backward(x, y, a, w, gamma, mean, invstd)
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        x, y, a, w, gamma, mean, invstd = ctx.saved_tensors
+        da = _f32c(da)
+        rb = ctx.rb
+        nIn, nOut = w.shape[1], w.shape[2]
+        n, dev = y.shape[0], y.device
+        L, st = lib(), _stream()
+        dy = torch.empty_like(y)
+        dres = torch.empty_like(y) if ctx.has_res else None
+        dg = torch.empty(nOut, dtype=torch.float32, device=dev) if ctx.has_affine else None
+        dbe = torch.empty(nOut, dtype=torch.float32, device=dev) if ctx.has_affine else None
+        check(L.sei_bn_backward(_ptr(y), _ptr(a), _ptr(da), n, nOut, _ptr(gamma), _ptr(mean), _ptr(invstd), ctx.leak,
+                                1 if ctx.training else 0, _ptr(dy), _ptr(dres), _ptr(dg), _ptr(dbe), st))
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((rb.n_src, nIn), dtype=torch.float32, device=dev)
+            check(L.sei_conv_backward_input(rb.h, _ptr(dy), _ptr(w), _ptr(dx), nIn, nOut, st))
+        if ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3]):
+            dw = torch.empty_like(w)
+            if ctx.has_bias:
+                db = torch.empty(nOut, dtype=torch.float32, device=dev)
+            check(L.sei_conv_backward_weight(rb.h, _ptr(x), _ptr(dy), _ptr(dw), _ptr(db), nIn, nOut, st))
+        return dx, None, dw, db, dg, dbe, None, None, None, None, None, None, dres
+
+
+def conv_bn_act(x, conv, bn, leak=1.0, residual=None):
+    """Fused ``conv -> bn (+ residual) -> LeakyReLU(leak)`` on SparseConvNetTensor ``x`` (conv: SubmanifoldConvolution
+    or Convolution module, bn: BatchNormalization module); returns the SparseConvNetTensor of the result."""
+    sp = _triple(x.spatial_size)
+    if isinstance(conv, Convolution):
+        rb = x.metadata.conv_rulebook(sp, conv.filter_size, conv.filter_stride)
+        out = SparseConvNetTensor(metadata=x.metadata, spatial_size=torch.LongTensor(rb.spatial_out))
+    else:
+        rb = x.metadata.subm_rulebook(sp, conv.filter_size)
+        out = SparseConvNetTensor(metadata=x.metadata, spatial_size=x.spatial_size)
+    out.features = _ConvBN.apply(_f32c(x.features), rb, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean,
+                                 bn.running_var, bn.eps, bn.momentum, bn.training, float(leak),
+                                 None if residual is None else _f32c(residual))
+    return out
 
 
 def residual_block_supported(nplanes):
@@ -346,8 +413,8 @@ def residual_block(x, conv1, bn1, conv2, bn2, leak1, leak2):
     out = SparseConvNetTensor(metadata=x.metadata, spatial_size=x.spatial_size)
     out.features = _ResidualBlock.apply(_f32c(x.features), rb, conv1.weight, conv1.bias, bn1.weight, bn1.bias,
                                         bn1.running_mean, bn1.running_var, conv2.weight, conv2.bias, bn2.weight, bn2.bias,
-                                        bn2.running_mean, bn2.running_var, bn1.eps, bn1.momentum, bn1.training,
-                                        float(leak1), float(leak2))
+                                        bn2.running_mean, bn2.running_var, (bn1.eps, bn1.momentum, bn1.training),
+                                        (bn2.eps, bn2.momentum, bn2.training), float(leak1), float(leak2))
     return out
 
 
