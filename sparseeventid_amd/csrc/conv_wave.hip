@@ -387,12 +387,21 @@ __global__ __launch_bounds__(64, wave_occ(NT, G)) void conv_wave_mfma_kernel(
         const int rows = left < TR ? (int)left : TR;
         for (int e = lane; e < PARTS * NC; e += 64) {
             const int part = e / NC, c = e - part * NC;
-            double s0 = 0.0, s1 = 0.0;
-            for (int r = part; r < rows; r += PARTS) {
-                const double v = (double)acc_tile[(size_t)r * NC + c];
-                s0 += v;
-                s1 += v * v;
+            // four independent fp64 chains (a single chain is latency-bound), combined in a fixed order
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
+            int r = part;
+            for (; r + 3 * PARTS < rows; r += 4 * PARTS) {
+                const double v0 = (double)acc_tile[(size_t)r * NC + c], v1 = (double)acc_tile[(size_t)(r + PARTS) * NC + c];
+                const double v2 = (double)acc_tile[(size_t)(r + 2 * PARTS) * NC + c], v3 = (double)acc_tile[(size_t)(r + 3 * PARTS) * NC + c];
+                a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+                q0 += v0 * v0; q1 += v1 * v1; q2 += v2 * v2; q3 += v3 * v3;
             }
+            for (; r < rows; r += PARTS) {
+                const double v = (double)acc_tile[(size_t)r * NC + c];
+                a0 += v;
+                q0 += v * v;
+            }
+            const double s0 = (a0 + a1) + (a2 + a3), s1 = (q0 + q1) + (q2 + q3);
             double *o = stats + ((size_t)tile * PARTS + part) * 2 * ldy + col0 + c;
             o[0] = s0;
             o[ldy] = s1;

@@ -128,6 +128,21 @@ __global__ __launch_bounds__(64) void finalize_kernel(const double *__restrict__
     }
 }
 
+// Many per-tile partial sums (conv epilogue) -> <= STATS_ROWS rows, coalesced: block j sums a contiguous run of rows,
+// thread = column; fixed order.  (finalize_kernel reads one column per wave: fed 50 000 rows directly it is a
+// latency-bound 8-byte-strided walk.)
+constexpr int STATS_ROWS = 512;
+__global__ __launch_bounds__(256) void stats_compress_kernel(const double *__restrict__ in, int64_t n_rows, int cols,
+                                                             double *__restrict__ out) {
+    const int64_t per = (n_rows + gridDim.x - 1) / gridDim.x;
+    const int64_t r0 = (int64_t)blockIdx.x * per, r1 = r0 + per < n_rows ? r0 + per : n_rows;
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        double s = 0.0;
+        for (int64_t r = r0; r < r1; r++) s += in[r * cols + c];
+        out[(size_t)blockIdx.x * cols + c] = s;
+    }
+}
+
 static int reduce_launch(int mode, const float *x, const float *y, const float *dy, int64_t n, int C, const float *mean,
                          const float *invstd, float leak, double **partial_out, int *blocks_out, hipStream_t st) {
     int vec = (C % 4 == 0) ? 4 : 1;
@@ -292,9 +307,18 @@ int bn_forward(const float *x, int64_t n, int C, const float *gamma, const float
         if (n == 0) return 0;
         if (stats) {
             // per-tile partial sums written by the convolution's epilogue: only the (fixed-order) finalize is left
-            if (n_parts > 0x7fffffff) SEI_FAIL("bn_forward: too many partial sums");
-            finalize_kernel<<<C, 64, 0, st>>>(stats, (int)n_parts, C, n, 0, eps, momentum, save_mean, save_invstd, rmean, rvar);
+            const double *src = stats;
+            double *small = nullptr;
+            int rows = (int)n_parts;
+            if (n_parts > 2 * STATS_ROWS) {
+                SEI_TRY(pool_alloc_t(&small, (size_t)STATS_ROWS * 2 * C, st));
+                stats_compress_kernel<<<STATS_ROWS, 256, 0, st>>>(stats, n_parts, 2 * C, small);
+                src = small;
+                rows = STATS_ROWS;
+            }
+            finalize_kernel<<<C, 64, 0, st>>>(src, rows, C, n, 0, eps, momentum, save_mean, save_invstd, rmean, rvar);
             SEI_LAUNCH_CHECK();
+            pool_free(small);
         } else {
             double *partial;
             int blocks;
