@@ -139,9 +139,12 @@ class Trainer:
 
 
     # ------------------------------------------------------------------ checkpoint / resume
-    # Lightning-layout checkpoints: {"state_dict": {"encoder.*", "head.*"}, "global_step", "optimizer"} --
-    # what ModelCheckpoint writes and what create_trainer.py:93-115 reads back
-    # (/root/reference/src/utils/create_trainer.py:83-115).
+    # state_dict-compatible checkpoints: {"state_dict": {"encoder.*", "head.*"}, "global_step", "optimizer"}.  The
+    # "state_dict" / "global_step" entries are what the reference reads back (create_trainer.py:93-115: it loads the
+    # ``encoder.*`` keys of ckpt["state_dict"]); Lightning's own "optimizer_states" / "lr_schedulers" / "epoch" / "loops"
+    # entries are NOT written: "optimizer" holds the Adam state of this Trainer's ONE flat parameter, so a reference
+    # ``fit(ckpt_path=...)`` can take the weights from these files but not resume its optimizer from them, and
+    # load_checkpoint() of a real Lightning file restores weights and step only (and says so).
     def state_dict(self):
         sd = {"encoder." + k: v for k, v in self.encoder.state_dict().items()}
         sd.update({"head." + k: v for k, v in self.head.state_dict().items()})
@@ -161,6 +164,9 @@ class Trainer:
             raise KeyError("checkpoint lacks %s%s" % (prefix, missing[0]))
         with torch.no_grad():                        # copy IN PLACE: parameters are views of the flat arena
             for k, t in own.items():
+                if tuple(sub[k].shape) != tuple(t.shape):    # copy_ would silently broadcast
+                    raise ValueError("checkpoint tensor %s%s has shape %s, the module expects %s"
+                                     % (prefix, k, tuple(sub[k].shape), tuple(t.shape)))
                 t.copy_(sub[k].to(t.device))
 
     def load_checkpoint(self, path, resume=True):
@@ -173,6 +179,10 @@ class Trainer:
             if "optimizer" in ck:
                 self.opt.load_state_dict(ck["optimizer"])
                 self.flat_param.grad = self.arena.grad[self.opt_start:]
+            elif "optimizer_states" in ck:
+                import warnings
+                warnings.warn("checkpoint carries Lightning optimizer_states (per-parameter Adam moments); only the weights "
+                              "and global_step were restored -- the optimizer starts from zero moments")
 
     def restore_encoder_only(self, path, freeze=True):
         """mode.weights_location + restore_encoder_only (create_trainer.py:93-106): load the ``encoder.*`` keys

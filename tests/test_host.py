@@ -142,3 +142,16 @@ def test_checkpoint_roundtrip_and_encoder_only_restore(tmp_path):
     assert all(torch.equal(v, enc_before[k]) for k, v in c.encoder.state_dict().items())
     assert not torch.equal(c.head.state_dict()["classification_head.labelneutID.2.weight"], head_before)
     assert "Img/s" in format_log_message({"loss/loss": 1.25}, 64, 3, dt=0.5, mode="train")
+    # a shape-mismatched tensor is an error, not a silent broadcast; a Lightning-style file warns about its optimizer state
+    import pytest
+    bad = dict(ck)
+    bad["state_dict"] = dict(ck["state_dict"])
+    bad["state_dict"]["encoder.initial_convolution.bias"] = torch.zeros(1)
+    torch.save(bad, str(tmp_path / "bad.ckpt"))
+    with pytest.raises(ValueError):
+        b.load_checkpoint(str(tmp_path / "bad.ckpt"))
+    lit = {"state_dict": ck["state_dict"], "global_step": 5, "optimizer_states": [{}], "lr_schedulers": []}
+    torch.save(lit, str(tmp_path / "lit.ckpt"))
+    with pytest.warns(UserWarning):
+        b.load_checkpoint(str(tmp_path / "lit.ckpt"))
+    assert b.global_step == 5
