@@ -1,18 +1,10 @@
-// Sparse convolution arithmetic for gfx950 (scn.SubmanifoldConvolution / scn.Convolution:
-// resnet.py:30-50,105-110; sparse_building_blocks.py:29-34,110-117).
-//
-// Forward / dX: output-stationary  gather -> MFMA -> LDS-accumulate.
-//   One 256-thread workgroup owns a tile of 256 (or 128) dst rows whose fp32 accumulators live in
-//   LDS.  It walks the filter offsets k; for each k the tile's rules are compacted into sub-chunks
-//   of 16 rules that are dealt round-robin to the wavefronts.  W[k] is streamed through LDS in
-//   slices of 16/32 input planes (double buffered, one barrier per slice) and shared by all waves;
-//   src feature rows are gathered straight into MFMA A-operand registers (float4 per lane, 64 B
-//   per rule row and step), multiplied with v_mfma_f32_16x16x4_f32 (exact fp32) and the 16xN
-//   results are added into the LDS tile (ds_add_f32; rows of one k are distinct and the k-phases
-//   are barrier-separated, so the sum order is fixed: run-to-run deterministic, no global atomics).
-//   Every dst row is written to HBM exactly once.
-// dW: per (k, split) workgroup reduces X[src]^T dY[dst] over its sub-chunks with the same MFMA
-//   (rules are the contraction dimension); partial slabs are summed in a fixed order.
+// Sparse convolution for gfx950, weight side (scn.SubmanifoldConvolution / scn.Convolution:
+// resnet.py:30-50,105-110; sparse_building_blocks.py:29-34,110-117):
+//   * weight re-layout for the forward / dX kernels (conv_fwd.hip: column-permuted panels; conv_wave.hip: natural
+//     layout, transposed + offset-flipped for dX);
+//   * dW: per (k, split, ci block) workgroup reduces X[src]^T dY[dst] over its sub-chunks with v_mfma_f32_16x16x4_f32
+//     (rules are the contraction dimension, 4 per MFMA); register-resident operands, no barrier in the main loop;
+//     partial slabs are summed in a fixed order (deterministic).
 #include "common.h"
 
 #include <stdlib.h>
@@ -22,10 +14,6 @@ namespace sei {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ inline f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
-
-__device__ inline void lds_add(float *p, float v) {
-    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
 
 // position of column c inside a column group of NT = width/16 tiles (see load_b in conv_fwd.hip)
 __device__ inline int permute_col(int c, int width) {

@@ -40,10 +40,6 @@ __device__ unsigned long long g_stamps[16];
 
 __device__ inline f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
-__device__ inline void lds_add(float *p, float v) {
-    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
 // unconditional load (clamped row) + select: conditional loads make hipcc serialise them with vmcnt(0)
 __device__ inline float4 load_a(const float *__restrict__ X, int src, int CIN, int off) {
     int row = src > 0 ? src : 0;
