@@ -11,7 +11,7 @@
 #include <stdlib.h>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int G, int D, int BAR>
+template <int G, int D, int BAR, int PAT = 0>
 __global__ __launch_bounds__(256) void k(const float *__restrict__ table, unsigned row_mask, const float *__restrict__ wsrc,
                                          float *out, int iters) {
     extern __shared__ float lds[];  // [2][3072] weight slices (32 planes x 96 columns)
@@ -43,8 +43,17 @@ __global__ __launch_bounds__(256) void k(const float *__restrict__ table, unsign
 #pragma unroll
         for (int q = 0; q < G; q++) {
             h = h * 1664525u + 1013904223u;
-            const unsigned row = (h >> 8) & row_mask;
-            a_n[q] = *reinterpret_cast<const float4 *>(table + (size_t)row * 96 + 16 * (q % 6) + 4 * g);
+            if (PAT == 0) {         // 16 rows x 64 B per wave-instruction (the conv kernels' A gather)
+                const unsigned row = (h >> 8) & row_mask;
+                a_n[q] = *reinterpret_cast<const float4 *>(table + (size_t)row * 96 + 16 * (q % 6) + 4 * g);
+            } else if (PAT == 1) {  // 4 rows x 256 B per wave-instruction
+                const unsigned row = (__shfl(h, g * 16) >> 8) & row_mask;
+                a_n[q] = *reinterpret_cast<const float4 *>(table + (size_t)row * 96 + 4 * r16);
+            } else {                // 1 KiB contiguous per wave-instruction (rows of 96 floats: spans 2.7 rows)
+                unsigned row = (__shfl(h, 0) >> 8) & row_mask;
+                row = row > 8 ? row - 8 : 0;   // the 1-KiB read spans 2.7 rows: stay inside the table
+                a_n[q] = *reinterpret_cast<const float4 *>(table + (size_t)row * 96 + 4 * lane);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         const float *wb = lds + (it & 1) * 3072;
@@ -68,15 +77,15 @@ __global__ __launch_bounds__(256) void k(const float *__restrict__ table, unsign
 
 static float *g_table, *g_w, *g_out;
 
-template <int G, int D, int BAR>
+template <int G, int D, int BAR, int PAT = 0>
 void run(int wgs_per_cu, unsigned row_mask, const char *where) {
     const int grid = 256 * wgs_per_cu, iters = 4000;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    k<G, D, BAR><<<grid, 256, 2 * 3072 * 4>>>(g_table, row_mask, g_w, g_out, 50);
+    k<G, D, BAR, PAT><<<grid, 256, 2 * 3072 * 4>>>(g_table, row_mask, g_w, g_out, 50);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    k<G, D, BAR><<<grid, 256, 2 * 3072 * 4>>>(g_table, row_mask, g_w, g_out, iters);
+    k<G, D, BAR, PAT><<<grid, 256, 2 * 3072 * 4>>>(g_table, row_mask, g_w, g_out, iters);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms;
@@ -84,8 +93,8 @@ void run(int wgs_per_cu, unsigned row_mask, const char *where) {
     const double flops = (double)grid * 4 * iters * 24 * 2048.0;
     // SIMD-cycles per iteration at the nominal 2.4 GHz (the chip's real clock under load is lower): each SIMD runs
     // wgs_per_cu waves, so one wave-iteration gets (ms * 2.4e6 cycles) / (iters * wgs_per_cu)
-    printf("G=%d D=%d BAR=%d %d WG/CU rows %-8s: %8.3f ms  %6.1f TFLOP/s  %7.0f nominal SIMD-cycles per wave-iteration (24 MFMA = 768)\n",
-           G, D, BAR, wgs_per_cu, where, ms, flops / ms / 1e9, ms * 2.4e6 / iters / wgs_per_cu);
+    printf("G=%d D=%d BAR=%d PAT=%d %d WG/CU rows %-8s: %8.3f ms  %6.1f TFLOP/s  %7.0f nominal SIMD-cycles per wave-iteration (24 MFMA = 768)\n",
+           G, D, BAR, PAT, wgs_per_cu, where, ms, flops / ms / 1e9, ms * 2.4e6 / iters / wgs_per_cu);
 }
 
 int main() {
@@ -99,11 +108,14 @@ int main() {
     for (int w = 1; w <= 3; w++) {
         run<0, 0, 0>(w, l2, "-");
         run<0, 0, 1>(w, l2, "-");
-        run<1, 0, 0>(w, l2, "L2"); run<2, 0, 0>(w, l2, "L2"); run<4, 0, 0>(w, l2, "L2");
+        run<1, 0, 0>(w, l2, "L2"); run<2, 0, 0>(w, l2, "L2"); run<4, 0, 0>(w, l2, "L2"); run<6, 0, 0>(w, l2, "L2"); run<8, 0, 0>(w, l2, "L2");
         run<2, 0, 0>(w, big, "HBM"); run<4, 0, 0>(w, big, "HBM");
         run<0, 1, 1>(w, l2, "-"); run<0, 3, 1>(w, l2, "-");
         run<2, 1, 1>(w, l2, "L2"); run<2, 3, 1>(w, l2, "L2"); run<2, 3, 1>(w, big, "HBM");
         run<4, 3, 1>(w, big, "HBM");
     }
+    // gather shape: 16 x 64 B (PAT 0) vs 4 x 256 B (PAT 1) vs 1 KiB contiguous (PAT 2) per wave-instruction
+    run<6, 0, 0, 1>(3, l2, "L2"); run<8, 0, 0, 1>(3, l2, "L2"); run<6, 0, 0, 2>(3, l2, "L2"); run<8, 0, 0, 2>(3, l2, "L2");
+    run<4, 0, 0, 1>(3, big, "HBM"); run<4, 0, 0, 2>(3, big, "HBM");
     return 0;
 }
