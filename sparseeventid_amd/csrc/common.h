@@ -240,7 +240,7 @@ int bn_forward(const float *x, int64_t n, int C, const float *gamma, const float
                float *save_invstd, hipStream_t st, const double *stats = nullptr, int64_t n_parts = 0);
 int bn_backward(const float *x, const float *y, const float *dy, int64_t n, int C, const float *gamma,
                 const float *save_mean, const float *save_invstd, float leak, int training, float *dx, float *dres,
-                float *dgamma, float *dbeta, hipStream_t st);
+                float *dgamma, float *dbeta, hipStream_t st, float *dx_colsum = nullptr);
 int leaky_forward(const float *x, float *y, int64_t count, float leak, hipStream_t st);
 int leaky_backward(const float *y, const float *dy, float *dx, int64_t count, float leak, hipStream_t st);
 int add_forward(const float *a, const float *b, float *out, int64_t count, float leak, bool act, hipStream_t st);

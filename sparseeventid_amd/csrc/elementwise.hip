@@ -230,10 +230,15 @@ __global__ void bn_bwd_apply_kernel(const float *__restrict__ x, const float *__
                                     const float *__restrict__ dy, float *__restrict__ dx, float *__restrict__ dres,
                                     int64_t total_vec, int C, const float *__restrict__ mean,
                                     const float *__restrict__ invstd, const float *__restrict__ gamma,
-                                    const float *__restrict__ coef /*[2][C] or null (eval)*/, float leak) {
+                                    const float *__restrict__ coef /*[2][C] or null (eval)*/, float leak,
+                                    double *__restrict__ dxsum /*[blocks][C] or null*/) {
+    __shared__ double colpart[256 * VEC];
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int c = (int)((t * VEC) % C);  // constant per thread: the grid is sized so that stride*VEC % C == 0
+    float cs[VEC];  // a thread sums only a few dozen values of one channel group: fp32 here, fp64 across threads
+#pragma unroll
+    for (int v = 0; v < VEC; v++) cs[v] = 0.f;
     float gs[VEC], is_[VEC], mu[VEC], c0[VEC], c1[VEC];
 #pragma unroll
     for (int v = 0; v < VEC; v++) {
@@ -272,7 +277,38 @@ __global__ void bn_bwd_apply_kernel(const float *__restrict__ x, const float *__
             dx[t] = o[0];
             if (dres) dres[t] = dz[0];
         }
+        if (dxsum) {
+#pragma unroll
+            for (int v = 0; v < VEC; v++) cs[v] += o[v];
+        }
     }
+    if (dxsum) {
+        // column sums of dx (= the bias gradient of the convolution that produced x) while dx is in registers:
+        // every thread owns one channel group; the block's threads of one channel are added in thread order
+        // (fixed order), one row of partial sums per block.  Needs C % VEC == 0 (host checks).
+#pragma unroll
+        for (int v = 0; v < VEC; v++) colpart[threadIdx.x * VEC + v] = (double)cs[v];
+        __syncthreads();
+        const int P = C / VEC;  // threads per channel period
+        const int64_t base = (int64_t)blockIdx.x * blockDim.x;
+        for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
+            const int gq = ch / VEC, v = ch - gq * VEC;
+            int i0 = (int)(((int64_t)gq - base % P + P) % P);
+            double acc = 0.0;
+            for (int i = i0; i < (int)blockDim.x; i += P) acc += colpart[i * VEC + v];
+            dxsum[(size_t)blockIdx.x * C + ch] = acc;
+        }
+    }
+}
+
+// out[c] = sum over rows b of partial[b][C] (one wave per channel, fixed-shape tree)
+__global__ __launch_bounds__(64) void colsum_rows_kernel(const double *__restrict__ partial, int rows, int C, float *out) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    double s = 0.0;
+    for (int b = lane; b < rows; b += 64) s += partial[(size_t)b * C + c];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_down(s, d);
+    if (lane == 0) out[c] = (float)s;
 }
 
 __global__ void eval_stats_kernel(const float *rmean, const float *rvar, float eps, int C, float *save_mean,
@@ -347,9 +383,10 @@ int bn_forward(const float *x, int64_t n, int C, const float *gamma, const float
 
 int bn_backward(const float *x, const float *y, const float *dy, int64_t n, int C, const float *gamma,
                 const float *save_mean, const float *save_invstd, float leak, int training, float *dx, float *dres,
-                float *dgamma, float *dbeta, hipStream_t st) {
+                float *dgamma, float *dbeta, hipStream_t st, float *dx_colsum) {
     ProfScope ps(PROF_BN, st, 0.0, (dres ? 32.0 : 28.0) * (double)n * C);
     if (n == 0) {
+        if (dx_colsum) SEI_HIP(hipMemsetAsync(dx_colsum, 0, C * sizeof(float), st));
         if (dgamma) SEI_HIP(hipMemsetAsync(dgamma, 0, C * sizeof(float), st));
         if (dbeta) SEI_HIP(hipMemsetAsync(dbeta, 0, C * sizeof(float), st));
         return 0;
@@ -363,14 +400,28 @@ int bn_backward(const float *x, const float *y, const float *dy, int64_t n, int 
     SEI_LAUNCH_CHECK();
     pool_free(partial);
     const float *cf = training ? coef : nullptr;
-    if (C % 4 == 0) {
-        int64_t tv = n * C / 4;
-        bn_bwd_apply_kernel<4><<<bn_blocks(tv, C, 4), 256, 0, st>>>(x, y, dy, dx, dres, tv, C, save_mean, save_invstd, gamma, cf, leak);
-    } else {
-        int64_t tv = n * C;
-        bn_bwd_apply_kernel<1><<<bn_blocks(tv, C, 1), 256, 0, st>>>(x, y, dy, dx, dres, tv, C, save_mean, save_invstd, gamma, cf, leak);
+    const int vec = C % 4 == 0 ? 4 : 1;
+    const int64_t tv = n * C / vec;
+    const unsigned nb = bn_blocks(tv, C, vec);
+    double *dxs = nullptr;
+    if (dx_colsum) SEI_TRY(pool_alloc_t(&dxs, (size_t)nb * C, st));
+    if (vec == 4)
+        bn_bwd_apply_kernel<4><<<nb, 256, 0, st>>>(x, y, dy, dx, dres, tv, C, save_mean, save_invstd, gamma, cf, leak, dxs);
+    else
+        bn_bwd_apply_kernel<1><<<nb, 256, 0, st>>>(x, y, dy, dx, dres, tv, C, save_mean, save_invstd, gamma, cf, leak, dxs);
+    if (dx_colsum) {
+        if (nb > 2 * STATS_ROWS) {  // coalesced compression first: a wave per channel walking 8192 rows is latency-bound
+            double *small;
+            SEI_TRY(pool_alloc_t(&small, (size_t)STATS_ROWS * C, st));
+            stats_compress_kernel<<<STATS_ROWS, 256, 0, st>>>(dxs, nb, C, small);
+            colsum_rows_kernel<<<C, 64, 0, st>>>(small, STATS_ROWS, C, dx_colsum);
+            pool_free(small);
+        } else {
+            colsum_rows_kernel<<<C, 64, 0, st>>>(dxs, (int)nb, C, dx_colsum);
+        }
     }
     SEI_LAUNCH_CHECK();
+    pool_free(dxs);
     pool_free(coef);
     return 0;
 }

@@ -310,21 +310,22 @@ class _ResidualBlock(torch.autograd.Function):
         vec = lambda: torch.empty(C, dtype=torch.float32, device=dev)
         # BN2 (+ skip + act) backward: dy2, and the skip branch's gradient dres
         dy2, dres, dg2, dbe2 = torch.empty_like(x), torch.empty_like(x), vec(), vec()
-        check(L.sei_bn_backward(_ptr(y2), _ptr(out), _ptr(dout), n, C, _ptr(g2), _ptr(m2), _ptr(s2), ctx.leak2, tr2,
-                                _ptr(dy2), _ptr(dres), _ptr(dg2), _ptr(dbe2), st))
-        dw2 = torch.empty_like(w2)
+        # the conv bias gradient = column sums of the BN backward's output, taken while it is written (no extra pass)
         db2 = vec() if ctx.has_b2 else None
-        check(L.sei_conv_backward_weight(rb.h, _ptr(a1), _ptr(dy2), _ptr(dw2), _ptr(db2), C, C, st))
+        check(L.sei_bn_backward_colsum(_ptr(y2), _ptr(out), _ptr(dout), n, C, _ptr(g2), _ptr(m2), _ptr(s2), ctx.leak2, tr2,
+                                       _ptr(dy2), _ptr(dres), _ptr(dg2), _ptr(dbe2), _ptr(db2), st))
+        dw2 = torch.empty_like(w2)
+        check(L.sei_conv_backward_weight(rb.h, _ptr(a1), _ptr(dy2), _ptr(dw2), None, C, C, st))
         da1 = torch.empty_like(x)
         check(L.sei_conv_backward_input(rb.h, _ptr(dy2), _ptr(w2), _ptr(da1), C, C, st))
         del dy2
         dy1, dg1, dbe1 = torch.empty_like(x), vec(), vec()
-        check(L.sei_bn_backward(_ptr(y1), _ptr(a1), _ptr(da1), n, C, _ptr(g1), _ptr(m1), _ptr(s1), ctx.leak1, tr1,
-                                _ptr(dy1), None, _ptr(dg1), _ptr(dbe1), st))
+        db1 = vec() if ctx.has_b1 else None
+        check(L.sei_bn_backward_colsum(_ptr(y1), _ptr(a1), _ptr(da1), n, C, _ptr(g1), _ptr(m1), _ptr(s1), ctx.leak1, tr1,
+                                       _ptr(dy1), None, _ptr(dg1), _ptr(dbe1), _ptr(db1), st))
         del da1
         dw1 = torch.empty_like(w1)
-        db1 = vec() if ctx.has_b1 else None
-        check(L.sei_conv_backward_weight(rb.h, _ptr(x), _ptr(dy1), _ptr(dw1), _ptr(db1), C, C, st))
+        check(L.sei_conv_backward_weight(rb.h, _ptr(x), _ptr(dy1), _ptr(dw1), None, C, C, st))
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
@@ -370,17 +371,17 @@ class _ConvBN(torch.autograd.Function):
         dres = torch.empty_like(y) if ctx.has_res else None
         dg = torch.empty(nOut, dtype=torch.float32, device=dev) if ctx.has_affine else None
         dbe = torch.empty(nOut, dtype=torch.float32, device=dev) if ctx.has_affine else None
-        check(L.sei_bn_backward(_ptr(y), _ptr(a), _ptr(da), n, nOut, _ptr(gamma), _ptr(mean), _ptr(invstd), ctx.leak,
-                                1 if ctx.training else 0, _ptr(dy), _ptr(dres), _ptr(dg), _ptr(dbe), st))
-        dx = dw = db = None
+        want_db = ctx.has_bias and ctx.needs_input_grad[3]
+        db = torch.empty(nOut, dtype=torch.float32, device=dev) if want_db else None
+        check(L.sei_bn_backward_colsum(_ptr(y), _ptr(a), _ptr(da), n, nOut, _ptr(gamma), _ptr(mean), _ptr(invstd), ctx.leak,
+                                       1 if ctx.training else 0, _ptr(dy), _ptr(dres), _ptr(dg), _ptr(dbe), _ptr(db), st))
+        dx = dw = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((rb.n_src, nIn), dtype=torch.float32, device=dev)
             check(L.sei_conv_backward_input(rb.h, _ptr(dy), _ptr(w), _ptr(dx), nIn, nOut, st))
-        if ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3]):
+        if ctx.needs_input_grad[2]:
             dw = torch.empty_like(w)
-            if ctx.has_bias:
-                db = torch.empty(nOut, dtype=torch.float32, device=dev)
-            check(L.sei_conv_backward_weight(rb.h, _ptr(x), _ptr(dy), _ptr(dw), _ptr(db), nIn, nOut, st))
+            check(L.sei_conv_backward_weight(rb.h, _ptr(x), _ptr(dy), _ptr(dw), None, nIn, nOut, st))
         return dx, None, dw, db, dg, dbe, None, None, None, None, None, None, dres
 
 
