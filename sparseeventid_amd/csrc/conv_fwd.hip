@@ -15,13 +15,18 @@
 //   no atomics; every dst row is written to HBM exactly once.  Tiles are sized so that 2-6 workgroups share
 //   a CU: the barrier / gather latency of one workgroup is covered by its neighbours' MFMAs.
 #include "common.h"
+#include "conv_tile.h"
 
 #include <stdlib.h>
 #include <string.h>
 
-namespace sei {
+#ifdef SEI_ABL_NOBAR  // diagnostic: the per-phase workgroup barrier removed (results are wrong, timing only)
+#define SEI_BARRIER_INSN "s_nop 0"
+#else
+#define SEI_BARRIER_INSN "s_barrier"
+#endif
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+namespace sei {
 
 // Diagnostic build only (make EXTRA=-DSEI_STAMPS; tools/stamps.py): wave 1 of every tile adds the s_memtime
 // ticks it spends in each part of the forward kernel to g_stamps.  The product build compiles none of it.
@@ -38,29 +43,16 @@ __device__ unsigned long long g_stamps[16];
 #define STAMP_FLUSH
 #endif
 
-__device__ inline f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
-
-// unconditional load (clamped row) + select: conditional loads make hipcc serialise them with vmcnt(0)
-__device__ inline float4 load_a(const float *__restrict__ X, int src, int CIN, int off) {
-    int row = src > 0 ? src : 0;
-#ifdef SEI_ABLATE_GATHER  // diagnostic: every gather hits the caches (results are wrong, timing only)
-    row &= 1023;
-#endif
-    float4 v = *reinterpret_cast<const float4 *>(X + (size_t)row * CIN + off);
-#ifndef SEI_TILE_NOSELECT
-    // Padding slots feed ZEROS to the MFMA.  Their output rows are never written back, so garbage would be equally
-    // correct -- but measured on one device (tools/tile_ab.sh, levels 1-3) zeros run 5-7 % faster than row-0 data
-    // (51.7 / 66.1 / 71.8 vs 49.2 / 61.9 / 68.5 TFLOP/s): the chip holds a higher clock on the ~10 % all-zero rows.
-    if (src < 0) v = make_float4(0.f, 0.f, 0.f, 0.f);
-#endif
-    return v;
-}
-
 // B operands of one input plane for the wave's NT column tiles.  The weight columns of every column
 // group are stored permuted (conv_permute_col) so that lane r16 finds the values of 4 (2, 1) column
 // tiles in ONE ds_read_b128 (b64, b32): position 64b + 4r + j holds column 64b + 16j + r.
 template <int NT>
 __device__ __forceinline__ void load_b(const float *__restrict__ wrow, int r16, float (&b)[NT]) {
+#ifdef SEI_ABL_NOB  // diagnostic: no LDS reads for the B operands
+#pragma unroll
+    for (int n = 0; n < NT; n++) b[n] = 1.0f + n;
+    return;
+#endif
     constexpr int B4 = NT / 4, REM = NT % 4;
 #pragma unroll
     for (int q = 0; q < B4; q++) {
@@ -98,24 +90,13 @@ __device__ __forceinline__ void compute_phase(const float *__restrict__ wb, cons
         for (int m = 0; m < MS; m++) {
             const float av = e == 0 ? a[m][jj].x : e == 1 ? a[m][jj].y : e == 2 ? a[m][jj].z : a[m][jj].w;
 #pragma unroll
-            for (int n = 0; n < NT; n++) acc[m][n] = mfma16(av, b[st & 1][n], acc[m][n]);
-        }
-    }
-}
-
-// Weight slice global -> LDS by LDS-DMA (global_load_lds_dwordx4): no staging registers, asynchronous.
-// The slice is contiguous in W; every wave-instruction moves 1 KiB (64 lanes x 16 B) to a
-// wave-uniform LDS base + lane*16.  PIECES = 1-KiB pieces per slice, dealt round-robin to the 4 waves.
-template <int PIECES>
-__device__ __forceinline__ void stage_slice(const float *__restrict__ wslice, float *wdst, int wave, int lane) {
-#pragma unroll
-    for (int q = 0; q < (PIECES + 3) / 4; q++) {
-        const int piece = q * 4 + wave;
-        if (piece < PIECES) {  // wave-uniform
-            const float *gp = wslice + (size_t)piece * 256 + lane * 4;
-            float *lp = wdst + (size_t)piece * 256;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gp,
-                                             (__attribute__((address_space(3))) void *)lp, 16, 0, 0);
+            for (int n = 0; n < NT; n++) {
+#ifdef SEI_ABL_NOMFMA  // diagnostic: one VALU fma instead of the MFMA (keeps the operand dependencies)
+                acc[m][n][0] = fmaf(av, b[st & 1][n], acc[m][n][0]);
+#else
+                acc[m][n] = mfma16(av, b[st & 1][n], acc[m][n]);
+#endif
+            }
         }
     }
 }
@@ -138,16 +119,16 @@ constexpr int occ_for(int maxs, int nt, int slj) {
 // NT = 16-column tiles per wave, CS = waves sharing one sub-chunk (column split), SLJ = slice / 16,
 // MAXS = sub-chunks of one offset a wave can own.  COUT = 16*NT*CS, tile rows TR = 16*MAXS*(4/CS).
 // LDS: acc[TR][COUT] | wbuf[2][SL][COUT] | seg[K+1]
-constexpr int APAD = 0;
+constexpr int APAD = 0;  // the shared tile helpers (conv_tile.h) assume an unpadded accumulator row stride
 
-template <int NT, int CS, int SLJ, int MAXS>
-__global__ __launch_bounds__(256, occ_for(MAXS, NT, SLJ)) void conv_tile_mfma_kernel(
+template <int NT, int CS, int SLJ, int MAXS, int NW = 4>
+__global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : occ_for(MAXS, NT, SLJ))) void conv_tile_mfma_kernel(
     const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ Y,
     const int32_t *__restrict__ tile_sub_start, const int32_t *__restrict__ tile_seg,
     const int32_t *__restrict__ sub_src, const uint8_t *__restrict__ sub_dst, int64_t n_dst, int K, int CIN, int n_tiles,
     const float *__restrict__ init, int ldy, int blocks, double *__restrict__ stats) {
     extern __shared__ float lds[];
-    constexpr int U = 4 / CS;  // units (groups of CS waves) dealing sub-chunks
+    constexpr int U = NW / CS;  // units (groups of CS waves) dealing sub-chunks
     constexpr int TR = 16 * MAXS * U;
     constexpr int SL = 16 * SLJ;
     constexpr int NC = NT * 16;
@@ -174,18 +155,8 @@ __global__ __launch_bounds__(256, occ_for(MAXS, NT, SLJ)) void conv_tile_mfma_ke
     int *seg = reinterpret_cast<int *>(wbuf + 2 * SL * COUT);
 
     STAMP_DECL;
-    for (int i = threadIdx.x; i <= K; i += 256) seg[i] = tile_seg[(size_t)tile * (K + 1) + i];
-    {
-        // accumulators start from the bias, or from the rows of `init` (Y = init + conv: gradient accumulation)
-        constexpr int V = COUT >> 2;
-        const int64_t row0i = (int64_t)tile * TR;
-        for (int idx = threadIdx.x; idx < TR * V; idx += 256) {
-            int r = idx / V, v = idx - r * V;
-            float4 b = bias ? *reinterpret_cast<const float4 *>(bias + 4 * v) : make_float4(0.f, 0.f, 0.f, 0.f);
-            if (init && row0i + r < n_dst) b = *reinterpret_cast<const float4 *>(init + (size_t)(row0i + r) * ldy + ycol0 + 4 * v);
-            *reinterpret_cast<float4 *>(acc_tile + (size_t)r * ASTRIDE + 4 * v) = b;
-        }
-    }
+    for (int i = threadIdx.x; i <= K; i += 64 * NW) seg[i] = tile_seg[(size_t)tile * (K + 1) + i];
+    tile_init<TR, COUT, 64 * NW>(acc_tile, bias, init, (int64_t)tile * TR, n_dst, ldy, ycol0);
     __syncthreads();
 
     const int64_t sub0 = tile_sub_start[tile];
@@ -202,9 +173,17 @@ __global__ __launch_bounds__(256, occ_for(MAXS, NT, SLJ)) void conv_tile_mfma_ke
         int s0 = __builtin_amdgcn_readfirstlane(seg[kk]), ns = __builtin_amdgcn_readfirstlane(seg[kk + 1]) - s0;
         if (k >= K) ns = 0;
         int ms = 0;
+        // The deal ROTATES with the offset: wave w of every workgroup sits on SIMD w, and a fixed deal (sub-chunk s to
+        // unit s mod U) would hand SIMD 0 the first -- often the only -- sub-chunk of every offset of every tile while
+        // SIMD 3 idles (tiles hold 1-3 sub-chunks per offset).  Which unit adds a sub-chunk does not change any sum.
+#ifdef SEI_TILE_NOROTATE
+        const int ru = unit;
+#else
+        const int ru = (unit + kk) % U;
+#endif
 #pragma unroll
         for (int m = 0; m < MAXS; m++) {
-            const int s = unit + m * U;
+            const int s = ru + m * U;
             const bool valid = s < ns;
             const int64_t sb = (sub0 + s0 + (valid ? s : 0)) * SUB_SLOTS;
             // the loaded values are NOT touched here: selecting on them would stall this wave for a full
@@ -221,7 +200,7 @@ __global__ __launch_bounds__(256, occ_for(MAXS, NT, SLJ)) void conv_tile_mfma_ke
     if (k < K) {
         int k1 = next_k(k), k2 = next_k(k1);
         RuleIdx<MAXS> ic = load_idx(k), in1 = load_idx(k1), in2 = load_idx(k2);
-        stage_slice<PIECES>(W + (size_t)k * CIN * COUT, wbuf, wave, lane);
+        stage_slice<PIECES, NW>(W + (size_t)k * CIN * COUT, wbuf, wave, lane);
         float4 a_c[MAXS][SLJ], a_n[MAXS][SLJ];
 #pragma unroll
         for (int m = 0; m < MAXS; m++)
@@ -251,9 +230,9 @@ __global__ __launch_bounds__(256, occ_for(MAXS, NT, SLJ)) void conv_tile_mfma_ke
                 // loads of offset k+2 issued just above -- a full memory latency per offset.  Those 2*MAXS loads are
                 // the youngest in flight (vmcnt retires in order), so leave exactly them outstanding.
                 if (s == 0 && phase > 0)
-                    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * MAXS) : "memory");
+                    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\t" SEI_BARRIER_INSN ::"n"(2 * MAXS) : "memory");
                 else
-                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" SEI_BARRIER_INSN ::: "memory");
                 STAMP(0);
                 if (s == 0) {
                     // the offset's products are summed from zero (see the write-back below)
@@ -265,8 +244,10 @@ __global__ __launch_bounds__(256, occ_for(MAXS, NT, SLJ)) void conv_tile_mfma_ke
                 STAMP(1);
                 // prefetch the next phase's weight slice and A fragments while this one computes
                 const bool same_k = s + 1 < NS;
-                stage_slice<PIECES>(W + ((size_t)(same_k ? k : kw) * CIN + (size_t)(same_k ? s + 1 : 0) * SL) * COUT,
+#ifndef SEI_ABL_NODMA
+                stage_slice<PIECES, NW>(W + ((size_t)(same_k ? k : kw) * CIN + (size_t)(same_k ? s + 1 : 0) * SL) * COUT,
                                     wbuf + (size_t)((phase + 1) & 1) * SL * COUT, wave, lane);
+#endif
                 const int aoff = (same_k ? (s + 1) * SL : 0) + 4 * g;
 #ifdef SEI_TILE_SKIP  // experiment: gather only the sub-chunks the wave owns in that phase
                 const int msn = same_k ? ic.ms : in1.ms;
@@ -312,6 +293,9 @@ __global__ __launch_bounds__(256, occ_for(MAXS, NT, SLJ)) void conv_tile_mfma_ke
             // order, and the fp32 chains stay short (nIn/4 MFMA steps, then one add per offset) like the
             // reference's per-offset  out[rows] += in[rows] @ W[k].  All reads of a sub-chunk are issued before
             // its adds (one LDS latency per sub-chunk and offset, covered by the CU's other waves).
+#ifdef SEI_ABL_NORMW  // diagnostic: accumulators are not added into the LDS tile
+            if (k == 1000000)
+#endif
 #pragma unroll
             for (int m = 0; m < MAXS; m++) {
                 if (m < ic.ms) {  // wave-uniform: one branch per sub-chunk, loads inside are unconditional
@@ -340,44 +324,9 @@ __global__ __launch_bounds__(256, occ_for(MAXS, NT, SLJ)) void conv_tile_mfma_ke
         }
     }
     __syncthreads();
-    // epilogue: every dst row is written once, as whole float4 row segments
-    constexpr int V = COUT >> 2;
     const int64_t row0 = (int64_t)tile * TR;
-    for (int idx = threadIdx.x; idx < TR * V; idx += 256) {
-        int r = idx / V, v = idx - r * V;
-        if (row0 + r < n_dst)
-            *reinterpret_cast<float4 *>(Y + (size_t)(row0 + r) * ldy + ycol0 + 4 * v) =
-                *reinterpret_cast<const float4 *>(acc_tile + (size_t)r * ASTRIDE + 4 * v);
-    }
-    if (stats) {
-        // BatchNorm statistics of the output while the tile is still in LDS: column sums over the tile's valid rows
-        // in fp64, PARTS row-interleaved partial sums per tile (fixed order: bit-identical reruns); the BN forward only
-        // finalizes them (no second read of Y).  Layout [tile * PARTS + part][2][ldy].
-        constexpr int PARTS = 256 / COUT > 0 ? 256 / COUT : 1;
-        const int64_t left = n_dst - row0;
-        const int rows = left < TR ? (int)left : TR;
-        for (int e = threadIdx.x; e < PARTS * COUT; e += 256) {
-            const int part = e / COUT, c = e - part * COUT;
-            // four independent fp64 chains (a single chain is latency-bound), combined in a fixed order
-            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
-            int r = part;
-            for (; r + 3 * PARTS < rows; r += 4 * PARTS) {
-                const double v0 = (double)acc_tile[(size_t)r * ASTRIDE + c], v1 = (double)acc_tile[(size_t)(r + PARTS) * ASTRIDE + c];
-                const double v2 = (double)acc_tile[(size_t)(r + 2 * PARTS) * ASTRIDE + c], v3 = (double)acc_tile[(size_t)(r + 3 * PARTS) * ASTRIDE + c];
-                a0 += v0; a1 += v1; a2 += v2; a3 += v3;
-                q0 += v0 * v0; q1 += v1 * v1; q2 += v2 * v2; q3 += v3 * v3;
-            }
-            for (; r < rows; r += PARTS) {
-                const double v = (double)acc_tile[(size_t)r * ASTRIDE + c];
-                a0 += v;
-                q0 += v * v;
-            }
-            const double s0 = (a0 + a1) + (a2 + a3), s1 = (q0 + q1) + (q2 + q3);
-            double *o = stats + ((size_t)tile * PARTS + part) * 2 * ldy + ycol0 + c;
-            o[0] = s0;
-            o[ldy] = s1;
-        }
-    }
+    tile_store<TR, COUT, 64 * NW>(acc_tile, Y, row0, n_dst, ldy, ycol0);
+    if (stats) tile_stats<TR, COUT, 64 * NW>(acc_tile, stats, tile, row0, n_dst, ldy, ycol0);
     STAMP(11);
     STAMP_ADD(7, 1);
     STAMP_FLUSH;
@@ -489,14 +438,16 @@ static size_t fwd_lds(int tile_rows, int nOut, int slj, int K) {
 
 // SEI_FWD_PLAN="maxs,cs,slj,nOut,blocks[;...]" overrides the default tiling of the layers with that nOut
 // (kernel experiments only)
-static bool env_plan(int nOut, int *maxs, int *cs, int *slj, int *blocks) {
+static bool env_plan(int nOut, int *maxs, int *cs, int *slj, int *blocks, int *nw) {
     const char *e = getenv("SEI_FWD_PLAN");
     while (e && *e) {
         int no = 0;
         *blocks = 1;
-        const int got = sscanf(e, "%d,%d,%d,%d,%d", maxs, cs, slj, &no, blocks);
+        *nw = 4;
+        const int got = sscanf(e, "%d,%d,%d,%d,%d,%d", maxs, cs, slj, &no, blocks, nw);
         if (got >= 4 && no == nOut) {
             if (got == 4) *blocks = 1;
+            if (got < 6) *nw = 4;
             return true;
         }
         e = strchr(e, ';');
@@ -529,16 +480,17 @@ static ConvPlan plan_tile(int nIn, int nOut, int K, int64_t n_dst) {
             }
         }
         p.slj = (nIn % 32 == 0) ? 2 : 1;
-        int em, ec, es, eb;
-        if (env_plan(nOut, &em, &ec, &es, &eb)) {
+        int em, ec, es, eb, ew;
+        if (env_plan(nOut, &em, &ec, &es, &eb, &ew)) {
             if (tiles % ec == 0 && em >= 1 && em <= 4 && (ec == 1 || ec == 2)) {
                 p.maxs = em; p.cs = ec; p.blocks = 1;
+                if (ew == 8 && ((ec == 1 && em == 1) || (ec == 2 && em == 2))) p.nw = 8;
                 if (es == 1 || (es == 2 && nIn % 32 == 0)) p.slj = es;
                 if (eb >= 1 && ec == 1 && tiles % eb == 0) p.blocks = eb;
             }
         }
         p.nt = tiles / p.cs / p.blocks;
-        p.tile_rows = 16 * p.maxs * (4 / p.cs);
+        p.tile_rows = 16 * p.maxs * (p.nw / p.cs);
         p.lds_bytes = fwd_lds(p.tile_rows, nOut / p.blocks, p.slj, K);
         if (p.lds_bytes > 160 * 1024) mfma = false;
     }
@@ -555,15 +507,17 @@ static ConvPlan plan_tile(int nIn, int nOut, int K, int64_t n_dst) {
 // the plan of one convolution call (forward, or dX with the plane counts swapped)
 ConvPlan plan_conv(int nIn, int nOut, int K, int64_t n_dst) {
     ConvPlan p{};
+    if (plan_units(nIn, nOut, K, n_dst, &p)) return p;
+    p = ConvPlan{};
     if (plan_wave(nIn, nOut, K, n_dst, &p)) return p;
     return plan_tile(nIn, nOut, K, n_dst);
 }
 
-template <int NT, int CS, int SLJ, int MAXS>
+template <int NT, int CS, int SLJ, int MAXS, int NW = 4>
 static int launch_mfma(const TiledRules &t, const ConvPlan &p, const float *X, const float *W, const float *bias,
                        float *Y, int nIn, const float *init, double *stats, hipStream_t st) {
-    SEI_TRY(ensure_max_lds((const void *)conv_tile_mfma_kernel<NT, CS, SLJ, MAXS>, 160 * 1024));
-    conv_tile_mfma_kernel<NT, CS, SLJ, MAXS><<<((t.n_tiles * p.blocks + 7) / 8) * 8, 256, p.lds_bytes, st>>>(
+    SEI_TRY(ensure_max_lds((const void *)conv_tile_mfma_kernel<NT, CS, SLJ, MAXS, NW>, 160 * 1024));
+    conv_tile_mfma_kernel<NT, CS, SLJ, MAXS, NW><<<((t.n_tiles * p.blocks + 7) / 8) * 8, 64 * NW, p.lds_bytes, st>>>(
         X, W, bias, Y, t.tile_sub_start, t.tile_seg, t.sub_src, t.sub_dst, t.n_dst, t.K, nIn, t.n_tiles, init,
         NT * CS * 16 * p.blocks, p.blocks, stats);
     SEI_LAUNCH_CHECK();
@@ -571,13 +525,21 @@ static int launch_mfma(const TiledRules &t, const ConvPlan &p, const float *X, c
 }
 
 #define FWD_CASE(NT_, CS_, SLJ_, MAXS_)                                            \
-    if (p.nt == NT_ && p.cs == CS_ && p.slj == SLJ_ && p.maxs == MAXS_)            \
+    if (p.nt == NT_ && p.cs == CS_ && p.slj == SLJ_ && p.maxs == MAXS_ && p.nw == 4) \
         return launch_mfma<NT_, CS_, SLJ_, MAXS_>(t, p, X, W, bias, Y, nIn, init, stats, st);
+#define FWD_CASE8(NT_)                                                             \
+    if (p.nt == NT_ && p.cs == 1 && p.maxs == 1 && p.nw == 8) {                    \
+        if (p.slj == 2) return launch_mfma<NT_, 1, 2, 1, 8>(t, p, X, W, bias, Y, nIn, init, stats, st); \
+        return launch_mfma<NT_, 1, 1, 1, 8>(t, p, X, W, bias, Y, nIn, init, stats, st);                 \
+    }
+#define FWD_CASE8C(NT_)                                                            \
+    if (p.nt == NT_ && p.cs == 2 && p.maxs == 2 && p.nw == 8 && p.slj == 2)       \
+        return launch_mfma<NT_, 2, 2, 2, 8>(t, p, X, W, bias, Y, nIn, init, stats, st);
 #define FWD_BOTH_SLJ(NT_, CS_, MAXS_) FWD_CASE(NT_, CS_, 1, MAXS_) FWD_CASE(NT_, CS_, 2, MAXS_)
 
 int64_t conv_stats_parts(const ConvPlan &p, const TiledRules &t) {
     if (t.n_dst == 0 || t.n_sub == 0) return 0;
-    if (p.kind == 1) {
+    if (p.kind == 1 || p.kind == 3) {
         const int cout = p.nt * p.cs * 16;
         return (int64_t)t.n_tiles * (256 / cout > 0 ? 256 / cout : 1);
     }
@@ -603,7 +565,11 @@ int conv_forward(const TiledRules &t, const float *X, const float *W, const floa
     if (p.tile_rows != t.tile_rows) SEI_FAIL("conv_forward: rulebook tile size does not match the kernel plan");
     if (stats && (p.kind == 0 || t.n_sub == 0)) SEI_FAIL("conv_forward: statistics are only produced by the MFMA kernels");
     if (p.kind == 2) return conv_forward_wave(t, p, X, W, bias, Y, nIn, nOut, init, stats, st);
+    if (p.kind == 3) return conv_forward_units(t, p, X, W, bias, Y, nIn, nOut, init, stats, st);
     if (p.kind == 1) {
+        // eight-wave workgroups (SEI_FWD_PLAN experiments)
+        FWD_CASE8(2) FWD_CASE8(3) FWD_CASE8(4) FWD_CASE8(5) FWD_CASE8(6)
+        FWD_CASE8C(2) FWD_CASE8C(3) FWD_CASE8C(4) FWD_CASE8C(5)
         // default plans
         FWD_BOTH_SLJ(1, 1, 2) FWD_BOTH_SLJ(2, 1, 2) FWD_BOTH_SLJ(3, 1, 2) FWD_BOTH_SLJ(4, 1, 2) FWD_BOTH_SLJ(5, 1, 2)
         FWD_BOTH_SLJ(6, 1, 2)

@@ -161,8 +161,8 @@ static int build_tiled(const int32_t *dst_coords, int64_t n_dst, int64_t n_src, 
     t.n_rules = (int64_t)host[0];
     t.n_sub = (int64_t)(uint32_t)host[2];
     int64_t ns = t.n_sub > 0 ? t.n_sub : 1;
-    SEI_TRY(pool_alloc_t(&t.sub_src, ns * SUB_SLOTS, st));
-    SEI_TRY(pool_alloc_t(&t.sub_dst, ns * SUB_SLOTS, st));
+    SEI_TRY(pool_alloc_t(&t.sub_src, (ns + 1) * SUB_SLOTS, st));  // +1: the kernels' clamped index prefetch may touch the sub-chunk after the last
+    SEI_TRY(pool_alloc_t(&t.sub_dst, (ns + 1) * SUB_SLOTS, st));
     tile_rules_kernel<true><<<t.n_tiles, tile_rows, 0, st>>>(nbr, K, tile_rows, t.n_tiles, nullptr, nullptr, nullptr,
                                                              nullptr, t.tile_sub_start, t.sub_src, t.sub_dst);
     SEI_LAUNCH_CHECK();

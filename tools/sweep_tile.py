@@ -12,6 +12,7 @@ def main():
     ap.add_argument("--level", type=int, default=2)
     ap.add_argument("--c", type=int, default=96)
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--rounds", type=int, default=4)
     ap.add_argument("--plans", nargs="*", default=["default"])
     a = ap.parse_args()
     from bench import generate_batch
@@ -32,28 +33,37 @@ def main():
     rb = t.metadata.subm_rulebook([int(v) for v in t.spatial_size], [3, 3, 3])
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ref = None
+    import statistics
+    times = {pl: [] for pl in a.plans}
+    errs = {}
+    R = rb.n_rules
+    for rnd in range(a.rounds):        # plans interleaved over several rounds: clocks drift during a run
+        for plan in a.plans:
+            if plan == "default":
+                os.environ.pop("SEI_FWD_PLAN", None)
+            else:
+                os.environ["SEI_FWD_PLAN"] = plan
+            try:
+                out = conv(tt); torch.cuda.synchronize()
+            except RuntimeError as e:
+                errs[plan] = "ERROR %s" % e
+                continue
+            if ref is None:
+                ref = out.features.detach().clone()
+            errs[plan] = "max diff %.1e" % float((out.features.detach() - ref).abs().max() / ref.abs().max())
+            ev0.record()
+            for _ in range(a.iters):
+                conv(tt)
+            ev1.record(); torch.cuda.synchronize()
+            times[plan].append(ev0.elapsed_time(ev1) / a.iters)
     for plan in a.plans:
-        if plan == "default":
-            os.environ.pop("SEI_FWD_PLAN", None)
-        else:
-            os.environ["SEI_FWD_PLAN"] = plan
-        try:
-            out = conv(tt); torch.cuda.synchronize()
-        except RuntimeError as e:
-            print("plan %-14s ERROR %s" % (plan, e), flush=True)
+        if not times[plan]:
+            print("plan %-16s %s" % (plan, errs.get(plan)), flush=True)
             continue
-        if ref is None:
-            ref = out.features.clone(); err = 0.0
-        else:
-            err = float((out.features - ref).abs().max() / ref.abs().max())
-        ev0.record()
-        for _ in range(a.iters):
-            conv(tt)
-        ev1.record(); torch.cuda.synchronize()
-        ms = ev0.elapsed_time(ev1) / a.iters
-        R = rb.n_rules
-        print("L%d C=%d N=%d plan %-14s fwd %.3f ms  %.1f TFLOP/s  (max diff %.1e)" % (
-            a.level, C, x.shape[0], plan, ms, 2.0 * R * C * C / ms / 1e9, err), flush=True)
+        ts = times[plan][1:] if len(times[plan]) > 1 else times[plan]   # round 0 = warm-up
+        med, best = statistics.median(ts), min(ts)
+        print("L%d C=%d N=%d plan %-16s fwd median %.3f ms %.1f TFLOP/s | best %.3f ms %.1f TFLOP/s  (%s)" % (
+            a.level, C, x.shape[0], plan, med, 2.0 * R * C * C / med / 1e9, best, 2.0 * R * C * C / best / 1e9, errs[plan]), flush=True)
 
 
 if __name__ == "__main__":
