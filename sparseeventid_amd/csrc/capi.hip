@@ -383,7 +383,7 @@ static int conv_forward_impl(sei_rulebook_t *rb, const float *X, const float *W,
         bias = ab.p;
     }
     const int kind = nIn == 32 && nOut == 32 ? PROF_CONV_FWD_C32 : PROF_CONV_FWD;
-    if (p.kind != 1 && p.kind != 3) {  // natural weight layout: no copy
+    if (p.kind != 1) {  // natural weight layout: no copy
         if (p.kind == 2) {
             SEI_TRY(aw.stage(W, (size_t)t->K * nIn * nOut, st));
             W = aw.p;
@@ -391,8 +391,7 @@ static int conv_forward_impl(sei_rulebook_t *rb, const float *X, const float *W,
         ProfScope ps(kind, st, 2.0 * t->n_rules * nIn * nOut, conv_bytes(*t, nIn, nOut));
         return conv_forward(*t, X, W, bias, Y, nIn, nOut, st, nullptr, stats);
     }
-    // the workgroup-tile MFMA kernels read B operands from LDS images of re-laid-out weights: column-permuted panels
-    // (kind 1) or B-fragment slices (kind 3) -- a tiny copy, <= 4 MB
+    // the workgroup-tile MFMA kernel reads B operands with wide LDS loads from column-permuted weights (tiny copy, <= 4 MB)
     float *Wp;
     SEI_TRY(pool_alloc_t(&Wp, (size_t)t->K * nIn * nOut, st));
     int rc = conv_transform_weights(W, Wp, t->K, nIn, nOut, false, false, p.col_group, p.blocks, st);
@@ -439,8 +438,8 @@ static int conv_backward_input_impl(sei_rulebook_t *rb, const float *dY, const f
     float *Wt;
     SEI_TRY(pool_alloc_t(&Wt, (size_t)t->K * nIn * nOut, st));
     // Wt[k'][co][ci] = W[K-1-k' (submanifold mirror) or k'][ci][co] (kind 1: columns (ci) permuted for the kernel)
-    int rc = conv_transform_weights(W, Wt, t->K, nIn, nOut, true, rb->submanifold, (p.kind == 1 || p.kind == 3) ? p.col_group : 0,
-                                    (p.kind == 1 || p.kind == 3) ? p.blocks : 1, st);
+    int rc = conv_transform_weights(W, Wt, t->K, nIn, nOut, true, rb->submanifold, p.kind == 1 ? p.col_group : 0,
+                                    p.kind == 1 ? p.blocks : 1, st);
     if (!rc) {
         ProfScope ps(nIn == 32 && nOut == 32 ? PROF_CONV_BWD_IN_C32 : PROF_CONV_BWD_IN, st, 2.0 * t->n_rules * nIn * nOut,
                      conv_bytes(*t, nOut, nIn));

@@ -209,11 +209,9 @@ int export_rules(const TiledRules &t, int64_t *start_host, int32_t *rin, int32_t
 // counts, the filter volume of the rulebook and the dst row count, and threaded through rulebook build, weight
 // transform and launch.
 struct ConvPlan {
-    int kind = 0;        // 0 scalar tile kernels (tiny / odd plane counts), 1 workgroup-tile MFMA kernel, 2 wave-private MFMA kernel,
-                         // 3 workgroup-tile MFMA kernel with unit dealing (conv_units.hip)
+    int kind = 0;        // 0 scalar tile kernels (tiny / odd plane counts), 1 workgroup-tile MFMA kernel, 2 wave-private MFMA kernel
     int tile_rows = 0;   // rulebook variant (dst rows per tile)
-    int col_group = 0;   // kind 1: width of the column groups whose columns are stored permuted (0 = natural layout);
-                         // kind 3: -(planes per weight slice): slices stored as MFMA B fragments [step][tile][lane]
+    int col_group = 0;   // kind 1: width of the column groups whose columns are stored permuted (0 = natural layout)
     int blocks = 1;      // column blocks (kind 1: weights stored as [block][K][nIn][nOut/blocks])
     int nt = 0, cs = 0, slj = 0, maxs = 0, g = 0;
     int nw = 4;          // kind 1: waves per workgroup (4 or 8)
@@ -221,7 +219,6 @@ struct ConvPlan {
 };
 ConvPlan plan_conv(int nIn, int nOut, int K, int64_t n_dst);
 bool plan_wave(int nIn, int nOut, int K, int64_t n_dst, ConvPlan *p);
-bool plan_units(int nIn, int nOut, int K, int64_t n_dst, ConvPlan *p);
 // stats (optional, MFMA kernels only): per-(tile, part) column sums of the OUTPUT rows, [n_parts][2][nOut] doubles
 // (sum, sum of squares) accumulated in the kernel epilogue from the LDS tile -- BatchNorm statistics without a second
 // read of the conv output.  conv_stats_parts() = how many parts this plan writes (0: the plan cannot).
@@ -229,12 +226,9 @@ int conv_forward(const TiledRules &t, const float *X, const float *W, const floa
                  hipStream_t st, const float *init = nullptr, double *stats = nullptr);
 int conv_forward_wave(const TiledRules &t, const ConvPlan &p, const float *X, const float *W, const float *bias, float *Y,
                       int nIn, int nOut, const float *init, double *stats, hipStream_t st);
-int conv_forward_units(const TiledRules &t, const ConvPlan &p, const float *X, const float *W, const float *bias, float *Y,
-                       int nIn, int nOut, const float *init, double *stats, hipStream_t st);
 int64_t conv_stats_parts(const ConvPlan &p, const TiledRules &t);
 // Wout[k][r][perm(c)]: transpose=false: rows=nIn, cols=nOut (forward); transpose=true: Wout[k][co][perm(ci)] = W[ks][ci][co]
-// with ks = flip ? K-1-k : k (dX).  perm = column permutation inside groups of `col_group` columns (0 = identity);
-// col_group < 0: every slice of -col_group rows is stored as MFMA B fragments (conv_units.hip).
+// with ks = flip ? K-1-k : k (dX).  perm = column permutation inside groups of `col_group` columns (0 = identity).
 int conv_transform_weights(const float *W, float *Wout, int K, int nIn, int nOut, bool transpose, bool flip, int col_group, int blocks,
                            hipStream_t st);
 int conv_backward_weight(const TiledRules &t, const float *X, const float *dY, float *dW, int nIn, int nOut,

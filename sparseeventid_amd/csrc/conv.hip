@@ -38,13 +38,6 @@ __device__ inline int permute_col(int c, int width) {
 // columns of every group permuted, or (blocks > 1) [block][K][rows][cols / blocks] so that each column block is
 // a contiguous panel for the workgroups that own it
 __device__ inline size_t weight_index(int ks, int row, int col, int K, int rows, int cols, int col_group, int blocks) {
-    if (col_group < 0) {
-        // conv_units.hip: [block][K][slice] panels of SL rows x w columns, each stored as B fragments: element
-        // (plane 16jj + 4g + e of the slice, column 16t + r) at [(4jj + e) * tiles + t][g][r]
-        const int SL = -col_group, w = cols / blocks, b = col / w, cl = col - b * w, t = cl >> 4, r = cl & 15, ntb = w >> 4;
-        const int s = row / SL, pr = row - s * SL, jj = pr >> 4, gq = (pr & 15) >> 2, e = pr & 3, st = 4 * jj + e;
-        return (((size_t)b * K + ks) * rows + (size_t)s * SL) * w + ((size_t)(st * ntb + t) * 64 + gq * 16 + r);
-    }
     const int pc = permute_col(col, col_group);
     if (blocks <= 1) return ((size_t)ks * rows + row) * cols + pc;
     const int w = cols / blocks, b = pc / w;

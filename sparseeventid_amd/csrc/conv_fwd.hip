@@ -2,7 +2,7 @@
 // resnet.py:30-50,105-110; sparse_building_blocks.py:29-34,110-117).
 //
 // Output-stationary  gather -> MFMA -> LDS-accumulate.
-//   One 256-thread workgroup owns a tile of TR (64/128/256) dst rows whose fp32 accumulators live
+//   One workgroup of 4 (or 8: NW) waves owns a tile of TR (64/128/256) dst rows whose fp32 accumulators live
 //   in LDS.  It walks the filter offsets k; for each k the tile's rules are compacted into
 //   sub-chunks of 16 rules that are dealt round-robin to the wavefronts.  W[k] is streamed through
 //   LDS by LDS-DMA in slices of 16/32 input planes (double buffered, ONE barrier per slice) and is
@@ -173,17 +173,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : occ_for(MAXS, NT, SLJ))) vo
         int s0 = __builtin_amdgcn_readfirstlane(seg[kk]), ns = __builtin_amdgcn_readfirstlane(seg[kk + 1]) - s0;
         if (k >= K) ns = 0;
         int ms = 0;
-        // The deal ROTATES with the offset: wave w of every workgroup sits on SIMD w, and a fixed deal (sub-chunk s to
-        // unit s mod U) would hand SIMD 0 the first -- often the only -- sub-chunk of every offset of every tile while
-        // SIMD 3 idles (tiles hold 1-3 sub-chunks per offset).  Which unit adds a sub-chunk does not change any sum.
-#ifdef SEI_TILE_NOROTATE
-        const int ru = unit;
-#else
-        const int ru = (unit + kk) % U;
-#endif
 #pragma unroll
         for (int m = 0; m < MAXS; m++) {
-            const int s = ru + m * U;
+            const int s = unit + m * U;
             const bool valid = s < ns;
             const int64_t sb = (sub0 + s0 + (valid ? s : 0)) * SUB_SLOTS;
             // the loaded values are NOT touched here: selecting on them would stall this wave for a full
@@ -436,7 +428,7 @@ static size_t fwd_lds(int tile_rows, int nOut, int slj, int K) {
     return ((size_t)tile_rows * (nOut + APAD) + 2 * 16 * slj * nOut) * sizeof(float) + (K + 1) * sizeof(int);
 }
 
-// SEI_FWD_PLAN="maxs,cs,slj,nOut,blocks[;...]" overrides the default tiling of the layers with that nOut
+// SEI_FWD_PLAN="maxs,cs,slj,nOut,blocks[,waves][;...]" overrides the default tiling of the layers with that nOut
 // (kernel experiments only)
 static bool env_plan(int nOut, int *maxs, int *cs, int *slj, int *blocks, int *nw) {
     const char *e = getenv("SEI_FWD_PLAN");
@@ -480,10 +472,19 @@ static ConvPlan plan_tile(int nIn, int nOut, int K, int64_t n_dst) {
             }
         }
         p.slj = (nIn % 32 == 0) ? 2 : 1;
+        if (nOut == 96) {
+            // 96 columns: eight-wave workgroups -- one sub-chunk per wave and offset on 128-row tiles, two column blocks
+            // of 48, 16-plane weight slices: 30 KB of LDS and ~60 VGPRs, four workgroups (32 waves) per CU.  A phase
+            // is one latency chain (barrier -> B from LDS -> MFMA -> LDS add) with little MFMA content; more
+            // independent chains per CU is what raises the MFMA rate: 74.4 vs 69.1 TFLOP/s at level 2 of the
+            // 64-event batch (profiles/r02_conv_units_experiment.log; 128 / 160 columns: +1-2 %, 192: slower).
+            p.nw = 8; p.maxs = 1; p.slj = 1; p.blocks = 2;
+        }
         int em, ec, es, eb, ew;
         if (env_plan(nOut, &em, &ec, &es, &eb, &ew)) {
             if (tiles % ec == 0 && em >= 1 && em <= 4 && (ec == 1 || ec == 2)) {
-                p.maxs = em; p.cs = ec; p.blocks = 1;
+                p.maxs = em; p.cs = ec; p.blocks = 1; p.nw = 4;
+                p.slj = (nIn % 32 == 0) ? 2 : 1;
                 if (ew == 8 && ((ec == 1 && em == 1) || (ec == 2 && em == 2))) p.nw = 8;
                 if (es == 1 || (es == 2 && nIn % 32 == 0)) p.slj = es;
                 if (eb >= 1 && ec == 1 && tiles % eb == 0) p.blocks = eb;
@@ -507,8 +508,6 @@ static ConvPlan plan_tile(int nIn, int nOut, int K, int64_t n_dst) {
 // the plan of one convolution call (forward, or dX with the plane counts swapped)
 ConvPlan plan_conv(int nIn, int nOut, int K, int64_t n_dst) {
     ConvPlan p{};
-    if (plan_units(nIn, nOut, K, n_dst, &p)) return p;
-    p = ConvPlan{};
     if (plan_wave(nIn, nOut, K, n_dst, &p)) return p;
     return plan_tile(nIn, nOut, K, n_dst);
 }
@@ -539,7 +538,7 @@ static int launch_mfma(const TiledRules &t, const ConvPlan &p, const float *X, c
 
 int64_t conv_stats_parts(const ConvPlan &p, const TiledRules &t) {
     if (t.n_dst == 0 || t.n_sub == 0) return 0;
-    if (p.kind == 1 || p.kind == 3) {
+    if (p.kind == 1) {
         const int cout = p.nt * p.cs * 16;
         return (int64_t)t.n_tiles * (256 / cout > 0 ? 256 / cout : 1);
     }
@@ -565,9 +564,8 @@ int conv_forward(const TiledRules &t, const float *X, const float *W, const floa
     if (p.tile_rows != t.tile_rows) SEI_FAIL("conv_forward: rulebook tile size does not match the kernel plan");
     if (stats && (p.kind == 0 || t.n_sub == 0)) SEI_FAIL("conv_forward: statistics are only produced by the MFMA kernels");
     if (p.kind == 2) return conv_forward_wave(t, p, X, W, bias, Y, nIn, nOut, init, stats, st);
-    if (p.kind == 3) return conv_forward_units(t, p, X, W, bias, Y, nIn, nOut, init, stats, st);
     if (p.kind == 1) {
-        // eight-wave workgroups (SEI_FWD_PLAN experiments)
+        // eight-wave workgroups (default for 96 columns; others through SEI_FWD_PLAN)
         FWD_CASE8(2) FWD_CASE8(3) FWD_CASE8(4) FWD_CASE8(5) FWD_CASE8(6)
         FWD_CASE8C(2) FWD_CASE8C(3) FWD_CASE8C(4) FWD_CASE8C(5)
         // default plans

@@ -1,4 +1,4 @@
-// Device helpers shared by the workgroup-tile convolution kernels (conv_fwd.hip, conv_units.hip): gfx950 only.
+// Device helpers shared by the workgroup-tile convolution kernels (conv_fwd.hip): gfx950 only.
 #pragma once
 #include "common.h"
 

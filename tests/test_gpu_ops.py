@@ -100,7 +100,7 @@ CONV_CASES = [(1, 32, [5, 5, 5]), (32, 32, [3, 3, 3]), (64, 64, [3, 3, 3]), (96,
               (256, 208, [1, 3, 3])]
 
 
-@pytest.mark.parametrize("kernel", ["default", "tile", "wave", "units"])
+@pytest.mark.parametrize("kernel", ["default", "tile", "wave"])
 @pytest.mark.parametrize("ci,co,filt", CONV_CASES)
 def test_subm_conv_forward_backward(ci, co, filt, kernel, monkeypatch):
     """`kernel` forces the workgroup-tile or the wave-private MFMA kernel (the library reads SEI_CONV_KERNEL per call)
@@ -132,7 +132,7 @@ def test_subm_conv_forward_backward(ci, co, filt, kernel, monkeypatch):
     assert rel_err(f.grad, fo.grad) < TOL
 
 
-@pytest.mark.parametrize("kernel", ["default", "tile", "wave", "units"])
+@pytest.mark.parametrize("kernel", ["default", "tile", "wave"])
 @pytest.mark.parametrize("ci,co,size", [(32, 64, [2, 2, 2]), (64, 96, [2, 2, 2]), (160, 192, [2, 2, 2]),
                                         (16, 32, [1, 2, 2]), (5, 7, [2, 2, 2]), (32, 32, [3, 3, 3])])
 def test_strided_conv_forward_backward(ci, co, size, kernel, monkeypatch):

@@ -16,16 +16,6 @@ PLANS = {
     160: ["tile", "5,64,2", "5,128,2", "5,64,3"],
     192: ["tile", "6,64,2", "6,64,3", "3,128,4", "4,64,2", "4,128,4"],
 }
-UPLANS = {
-    32: ["tile", "default", "u:2,128", "u:2,64"],
-    64: ["tile", "default", "u:4,128", "u:4,64", "u:2,128"],
-    96: ["tile", "u:6,128", "u:3,128", "u:6,64", "u:3,64", "u:2,128"],
-    128: ["tile", "u:4,128", "u:4,64", "u:2,128"],
-    160: ["tile", "u:5,128", "u:5,64", "u:2,128"],
-    192: ["tile", "u:6,128", "u:4,128", "u:6,64", "u:4,64", "u:3,128"],
-}
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--events", type=int, default=16)
@@ -33,7 +23,6 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--bwd", action="store_true")
     ap.add_argument("--only", nargs="*", default=None, help="restrict to these plan names (e.g. tile)")
-    ap.add_argument("--units", action="store_true", help="unit-dealing tile kernel plans (u:NT,TR -> SEI_UNITS_PLAN) next to the tile kernel and the default plan")
     ap.add_argument("--workers", type=int, default=int(os.environ.get("SEI_GEN_WORKERS", "0")) or min(16, os.cpu_count() or 8))
     a = ap.parse_args()
     from bench import generate_batch
@@ -56,17 +45,13 @@ def main():
             conv = scn.SubmanifoldConvolution(3, C, C, 3, True).cuda()
             rb = t.metadata.subm_rulebook(sp, [3, 3, 3])
             ref = None
-            for plan in (UPLANS[C] if a.units else PLANS[C]):
+            for plan in PLANS[C]:
                 if a.only is not None and plan not in a.only:
                     continue
-                os.environ.pop("SEI_UNITS_PLAN", None)
                 if plan == "tile":
                     os.environ["SEI_CONV_KERNEL"] = "tile"
                 elif plan == "default":
                     os.environ.pop("SEI_CONV_KERNEL", None)
-                elif plan.startswith("u:"):
-                    os.environ["SEI_CONV_KERNEL"] = "units"
-                    os.environ["SEI_UNITS_PLAN"] = "%d:%s" % (C, plan[2:])
                 else:
                     os.environ["SEI_CONV_KERNEL"] = "wave"
                     os.environ["SEI_WAVE_PLAN"] = "%d:%s" % (C, plan)
