@@ -134,10 +134,12 @@ int sei_bn_backward(const float *x, const float *y, const float *dy, int64_t n, 
 
 /* Same, and dx_colsum[C] (non-NULL) receives the column sums of dx computed while dx is written: when x is the output
  * of a convolution with a bias (Block.forward, sparse_building_blocks.py:47-57) that is the bias gradient, so
- * sei_conv_backward_weight can be called with dbias = NULL (no extra read of dx). */
+ * sei_conv_backward_weight can be called with dbias = NULL (no extra read of dx).
+ * y may be NULL when the forward had no residual (dresidual must be NULL too): the LeakyReLU mask is then recomputed
+ * from x, gamma and beta exactly as the forward computed it -- one tensor read less in each of the two passes. */
 int sei_bn_backward_colsum(const float *x, const float *y, const float *dy, int64_t n, int32_t C,
-                           const float *gamma, const float *save_mean, const float *save_invstd, float leak,
-                           int32_t training, float *dx, float *dresidual, float *dgamma, float *dbeta,
+                           const float *gamma, const float *beta, const float *save_mean, const float *save_invstd,
+                           float leak, int32_t training, float *dx, float *dresidual, float *dgamma, float *dbeta,
                            float *dx_colsum, sei_stream_t stream);
 
 /* ---- elementwise (scn.LeakyReLU / scn.ReLU / scn.AddTable) -------------------------------- */

@@ -44,7 +44,7 @@ _SIGNATURES = {
                                            ctypes.c_float, ctypes.c_int32, ctypes.c_float, vp, vp, vp, vp, vp]),
     "sei_bn_backward": (ctypes.c_int, [vp, vp, vp, ctypes.c_int64, ctypes.c_int32, vp, vp, vp, ctypes.c_float,
                                        ctypes.c_int32, vp, vp, vp, vp, vp]),
-    "sei_bn_backward_colsum": (ctypes.c_int, [vp, vp, vp, ctypes.c_int64, ctypes.c_int32, vp, vp, vp, ctypes.c_float,
+    "sei_bn_backward_colsum": (ctypes.c_int, [vp, vp, vp, ctypes.c_int64, ctypes.c_int32, vp, vp, vp, vp, ctypes.c_float,
                                               ctypes.c_int32, vp, vp, vp, vp, vp, vp]),
     "sei_leaky_forward": (ctypes.c_int, [vp, vp, ctypes.c_int64, ctypes.c_float, vp]),
     "sei_leaky_backward": (ctypes.c_int, [vp, vp, vp, ctypes.c_int64, ctypes.c_float, vp]),

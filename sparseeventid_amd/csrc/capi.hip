@@ -490,10 +490,12 @@ int sei_bn_backward(const float *x, const float *y, const float *dy, int64_t n, 
 }
 
 int sei_bn_backward_colsum(const float *x, const float *y, const float *dy, int64_t n, int32_t C, const float *gamma,
-                           const float *save_mean, const float *save_invstd, float leak, int32_t training, float *dx,
-                           float *dresidual, float *dgamma, float *dbeta, float *dx_colsum, sei_stream_t stream) {
+                           const float *beta, const float *save_mean, const float *save_invstd, float leak,
+                           int32_t training, float *dx, float *dresidual, float *dgamma, float *dbeta, float *dx_colsum,
+                           sei_stream_t stream) {
+    if (!y && dresidual) SEI_FAIL("sei_bn_backward_colsum: y may only be NULL when the forward had no residual");
     return bn_backward(x, y, dy, n, C, gamma, save_mean, save_invstd, leak, training, dx, dresidual, dgamma, dbeta,
-                       (hipStream_t)stream, dx_colsum);
+                       (hipStream_t)stream, dx_colsum, beta);
 }
 
 int sei_leaky_forward(const float *x, float *y, int64_t count, float leak, sei_stream_t stream) {

@@ -239,9 +239,10 @@ int colsum(const float *x, int64_t n, int C, float *out, hipStream_t st);
 int bn_forward(const float *x, int64_t n, int C, const float *gamma, const float *beta, float *rmean, float *rvar,
                float eps, float momentum, int training, float leak, const float *residual, float *y, float *save_mean,
                float *save_invstd, hipStream_t st, const double *stats = nullptr, int64_t n_parts = 0);
+// y == nullptr (only without a residual; needs beta): the activation mask is recomputed from x -- one read less per pass
 int bn_backward(const float *x, const float *y, const float *dy, int64_t n, int C, const float *gamma,
                 const float *save_mean, const float *save_invstd, float leak, int training, float *dx, float *dres,
-                float *dgamma, float *dbeta, hipStream_t st, float *dx_colsum = nullptr);
+                float *dgamma, float *dbeta, hipStream_t st, float *dx_colsum = nullptr, const float *beta = nullptr);
 int leaky_forward(const float *x, float *y, int64_t count, float leak, hipStream_t st);
 int leaky_backward(const float *y, const float *dy, float *dx, int64_t count, float leak, hipStream_t st);
 int add_forward(const float *a, const float *b, float *out, int64_t count, float leak, bool act, hipStream_t st);

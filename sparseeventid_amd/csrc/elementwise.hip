@@ -17,7 +17,9 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float *__restrict_
                                                         const float *__restrict__ dy, int64_t n, int C,
                                                         const float *__restrict__ mean,
                                                         const float *__restrict__ invstd, float leak,
-                                                        double *__restrict__ partial /*[blocks][2][C]*/) {
+                                                        double *__restrict__ partial /*[blocks][2][C]*/,
+                                                        const float *__restrict__ gamma = nullptr,
+                                                        const float *__restrict__ beta = nullptr) {
     extern __shared__ double lds_d[];  // [rl][2][C]
     const int cv = C / VEC;            // column groups
     const int rl = 256 / cv;           // row lanes
@@ -26,12 +28,15 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float *__restrict_
 #pragma unroll
     for (int v = 0; v < VEC; v++) s0[v] = s1[v] = 0.0;
     if (rlane < rl) {
-        float mu[VEC], is[VEC];
+        float mu[VEC], is[VEC], sc[VEC], sh[VEC];
         if (MODE == 1) {
 #pragma unroll
             for (int v = 0; v < VEC; v++) {
                 mu[v] = mean[col * VEC + v];
                 is[v] = invstd[col * VEC + v];
+                // y == null: the activation mask is recomputed from x exactly as the forward computed z (bn_apply_kernel)
+                sc[v] = is[v] * (gamma ? gamma[col * VEC + v] : 1.f);
+                sh[v] = beta ? beta[col * VEC + v] : 0.f;
             }
         }
         const int64_t rows_per_block = (n + gridDim.x - 1) / gridDim.x;
@@ -44,15 +49,17 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float *__restrict_
                 float4 t = *reinterpret_cast<const float4 *>(x + off);
                 xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
                 if (MODE == 1) {
-                    float4 u = *reinterpret_cast<const float4 *>(y + off);
-                    yv[0] = u.x; yv[1] = u.y; yv[2] = u.z; yv[3] = u.w;
+                    if (y) {
+                        float4 u = *reinterpret_cast<const float4 *>(y + off);
+                        yv[0] = u.x; yv[1] = u.y; yv[2] = u.z; yv[3] = u.w;
+                    }
                     float4 w = *reinterpret_cast<const float4 *>(dy + off);
                     dv[0] = w.x; dv[1] = w.y; dv[2] = w.z; dv[3] = w.w;
                 }
             } else {
                 xv[0] = x[off];
                 if (MODE == 1) {
-                    yv[0] = y[off];
+                    if (y) yv[0] = y[off];
                     dv[0] = dy[off];
                 }
             }
@@ -63,6 +70,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float *__restrict_
                     s0[v] += d;
                     s1[v] += d * d;
                 } else if (MODE == 1) {
+                    if (!y) yv[v] = (xv[v] - mu[v]) * sc[v] + sh[v];
                     float dz = yv[v] > 0.f ? dv[v] : dv[v] * leak;
                     float xh = (xv[v] - mu[v]) * is[v];
                     s0[v] += (double)dz;
@@ -144,7 +152,8 @@ __global__ __launch_bounds__(256) void stats_compress_kernel(const double *__res
 }
 
 static int reduce_launch(int mode, const float *x, const float *y, const float *dy, int64_t n, int C, const float *mean,
-                         const float *invstd, float leak, double **partial_out, int *blocks_out, hipStream_t st) {
+                         const float *invstd, float leak, double **partial_out, int *blocks_out, hipStream_t st,
+                         const float *gamma = nullptr, const float *beta = nullptr) {
     int vec = (C % 4 == 0) ? 4 : 1;
     int cv = C / vec;
     if (cv > 256) SEI_FAIL("channel count too large for the reduction kernel (max 1024 with C%4==0, else 256)");
@@ -154,7 +163,7 @@ static int reduce_launch(int mode, const float *x, const float *y, const float *
     double *partial;
     SEI_TRY(pool_alloc_t(&partial, (size_t)blocks * 2 * C, st));
     size_t lds = (size_t)rl * 2 * C * sizeof(double);
-#define RL(MODE, VEC) colreduce_kernel<MODE, VEC><<<blocks, 256, lds, st>>>(x, y, dy, n, C, mean, invstd, leak, partial)
+#define RL(MODE, VEC) colreduce_kernel<MODE, VEC><<<blocks, 256, lds, st>>>(x, y, dy, n, C, mean, invstd, leak, partial, gamma, beta)
     if (vec == 4) {
         if (mode == 0) RL(0, 4); else if (mode == 1) RL(1, 4); else RL(2, 4);
     } else {
@@ -231,7 +240,8 @@ __global__ void bn_bwd_apply_kernel(const float *__restrict__ x, const float *__
                                     int64_t total_vec, int C, const float *__restrict__ mean,
                                     const float *__restrict__ invstd, const float *__restrict__ gamma,
                                     const float *__restrict__ coef /*[2][C] or null (eval)*/, float leak,
-                                    double *__restrict__ dxsum /*[blocks][C] or null*/) {
+                                    double *__restrict__ dxsum /*[blocks][C] or null*/,
+                                    const float *__restrict__ beta /*only read when y == null*/) {
     __shared__ double colpart[256 * VEC];
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -239,11 +249,13 @@ __global__ void bn_bwd_apply_kernel(const float *__restrict__ x, const float *__
     float cs[VEC];  // a thread sums only a few dozen values of one channel group: fp32 here, fp64 across threads
 #pragma unroll
     for (int v = 0; v < VEC; v++) cs[v] = 0.f;
-    float gs[VEC], is_[VEC], mu[VEC], c0[VEC], c1[VEC];
+    float gs[VEC], is_[VEC], mu[VEC], c0[VEC], c1[VEC], sc[VEC], sh[VEC];
 #pragma unroll
     for (int v = 0; v < VEC; v++) {
         is_[v] = invstd[c + v];
         gs[v] = (gamma ? gamma[c + v] : 1.f) * is_[v];
+        sc[v] = is_[v] * (gamma ? gamma[c + v] : 1.f);  // y == null: mask from z recomputed as bn_apply_kernel computed it
+        sh[v] = (!y && beta) ? beta[c + v] : 0.f;
         mu[v] = mean[c + v];
         c0[v] = coef ? coef[c + v] : 0.f;
         c1[v] = coef ? coef[C + c + v] : 0.f;
@@ -253,15 +265,18 @@ __global__ void bn_bwd_apply_kernel(const float *__restrict__ x, const float *__
         if (VEC == 4) {
             float4 a = reinterpret_cast<const float4 *>(x)[t];
             xv[0] = a.x; xv[1] = a.y; xv[2] = a.z; xv[3] = a.w;
-            float4 b = reinterpret_cast<const float4 *>(y)[t];
-            yv[0] = b.x; yv[1] = b.y; yv[2] = b.z; yv[3] = b.w;
+            if (y) {
+                float4 b = reinterpret_cast<const float4 *>(y)[t];
+                yv[0] = b.x; yv[1] = b.y; yv[2] = b.z; yv[3] = b.w;
+            }
             float4 d = reinterpret_cast<const float4 *>(dy)[t];
             dv[0] = d.x; dv[1] = d.y; dv[2] = d.z; dv[3] = d.w;
         } else {
-            xv[0] = x[t]; yv[0] = y[t]; dv[0] = dy[t];
+            xv[0] = x[t]; if (y) yv[0] = y[t]; dv[0] = dy[t];
         }
 #pragma unroll
         for (int v = 0; v < VEC; v++) {
+            if (!y) yv[v] = (xv[v] - mu[v]) * sc[v] + sh[v];
             dz[v] = yv[v] > 0.f ? dv[v] : dv[v] * leak;
             if (coef) {
                 float xh = (xv[v] - mu[v]) * is_[v];
@@ -383,8 +398,10 @@ int bn_forward(const float *x, int64_t n, int C, const float *gamma, const float
 
 int bn_backward(const float *x, const float *y, const float *dy, int64_t n, int C, const float *gamma,
                 const float *save_mean, const float *save_invstd, float leak, int training, float *dx, float *dres,
-                float *dgamma, float *dbeta, hipStream_t st, float *dx_colsum) {
-    ProfScope ps(PROF_BN, st, 0.0, (dres ? 32.0 : 28.0) * (double)n * C);
+                float *dgamma, float *dbeta, hipStream_t st, float *dx_colsum, const float *beta) {
+    if (!y && dres) SEI_FAIL("bn_backward: y may only be omitted when the forward had no residual");
+    // bytes: the reduction reads x, (y), dy; the apply pass reads them again and writes dx (and dresidual)
+    ProfScope ps(PROF_BN, st, 0.0, ((y ? 28.0 : 20.0) + (dres ? 4.0 : 0.0)) * (double)n * C);
     if (n == 0) {
         if (dx_colsum) SEI_HIP(hipMemsetAsync(dx_colsum, 0, C * sizeof(float), st));
         if (dgamma) SEI_HIP(hipMemsetAsync(dgamma, 0, C * sizeof(float), st));
@@ -395,7 +412,7 @@ int bn_backward(const float *x, const float *y, const float *dy, int64_t n, int 
     SEI_TRY(pool_alloc_t(&coef, 2 * C, st));
     double *partial;
     int blocks;
-    SEI_TRY(reduce_launch(1, x, y, dy, n, C, save_mean, save_invstd, leak, &partial, &blocks, st));
+    SEI_TRY(reduce_launch(1, x, y, dy, n, C, save_mean, save_invstd, leak, &partial, &blocks, st, gamma, beta));
     finalize_kernel<<<C, 64, 0, st>>>(partial, blocks, C, n, 1, 0.f, 0.f, coef, coef + C, dgamma, dbeta);
     SEI_LAUNCH_CHECK();
     pool_free(partial);
@@ -406,9 +423,9 @@ int bn_backward(const float *x, const float *y, const float *dy, int64_t n, int 
     double *dxs = nullptr;
     if (dx_colsum) SEI_TRY(pool_alloc_t(&dxs, (size_t)nb * C, st));
     if (vec == 4)
-        bn_bwd_apply_kernel<4><<<nb, 256, 0, st>>>(x, y, dy, dx, dres, tv, C, save_mean, save_invstd, gamma, cf, leak, dxs);
+        bn_bwd_apply_kernel<4><<<nb, 256, 0, st>>>(x, y, dy, dx, dres, tv, C, save_mean, save_invstd, gamma, cf, leak, dxs, beta);
     else
-        bn_bwd_apply_kernel<1><<<nb, 256, 0, st>>>(x, y, dy, dx, dres, tv, C, save_mean, save_invstd, gamma, cf, leak, dxs);
+        bn_bwd_apply_kernel<1><<<nb, 256, 0, st>>>(x, y, dy, dx, dres, tv, C, save_mean, save_invstd, gamma, cf, leak, dxs, beta);
     if (dx_colsum) {
         if (nb > 2 * STATS_ROWS) {  // coalesced compression first: a wave per channel walking 8192 rows is latency-bound
             double *small;

@@ -294,12 +294,12 @@ class _ResidualBlock(torch.autograd.Function):
                                     _ptr(s2), st))
         ctx.rb, ctx.training1, ctx.training2, ctx.leak1, ctx.leak2 = rb, training1, training2, leak1, leak2
         ctx.has_b1, ctx.has_b2 = b1 is not None, b2 is not None
-        ctx.save_for_backward(x, y1, a1, y2, out, w1, w2, g1, g2, m1, s1, m2, s2)
+        ctx.save_for_backward(x, y1, a1, y2, out, w1, w2, g1, g2, m1, s1, m2, s2, be1)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x, y1, a1, y2, out, w1, w2, g1, g2, m1, s1, m2, s2 = ctx.saved_tensors
+        x, y1, a1, y2, out, w1, w2, g1, g2, m1, s1, m2, s2, be1 = ctx.saved_tensors
         dout = _f32c(dout)
         n, C = x.shape
         dev = x.device
@@ -312,8 +312,8 @@ class _ResidualBlock(torch.autograd.Function):
         dy2, dres, dg2, dbe2 = torch.empty_like(x), torch.empty_like(x), vec(), vec()
         # the conv bias gradient = column sums of the BN backward's output, taken while it is written (no extra pass)
         db2 = vec() if ctx.has_b2 else None
-        check(L.sei_bn_backward_colsum(_ptr(y2), _ptr(out), _ptr(dout), n, C, _ptr(g2), _ptr(m2), _ptr(s2), ctx.leak2, tr2,
-                                       _ptr(dy2), _ptr(dres), _ptr(dg2), _ptr(dbe2), _ptr(db2), st))
+        check(L.sei_bn_backward_colsum(_ptr(y2), _ptr(out), _ptr(dout), n, C, _ptr(g2), None, _ptr(m2), _ptr(s2), ctx.leak2,
+                                       tr2, _ptr(dy2), _ptr(dres), _ptr(dg2), _ptr(dbe2), _ptr(db2), st))
         dw2 = torch.empty_like(w2)
         check(L.sei_conv_backward_weight(rb.h, _ptr(a1), _ptr(dy2), _ptr(dw2), None, C, C, st))
         da1 = torch.empty_like(x)
@@ -321,8 +321,9 @@ class _ResidualBlock(torch.autograd.Function):
         del dy2
         dy1, dg1, dbe1 = torch.empty_like(x), vec(), vec()
         db1 = vec() if ctx.has_b1 else None
-        check(L.sei_bn_backward_colsum(_ptr(y1), _ptr(a1), _ptr(da1), n, C, _ptr(g1), _ptr(m1), _ptr(s1), ctx.leak1, tr1,
-                                       _ptr(dy1), None, _ptr(dg1), _ptr(dbe1), _ptr(db1), st))
+        # no residual behind BN1: the activation mask is recomputed from y1 (a1 is not read)
+        check(L.sei_bn_backward_colsum(_ptr(y1), None, _ptr(da1), n, C, _ptr(g1), _ptr(be1), _ptr(m1), _ptr(s1), ctx.leak1,
+                                       tr1, _ptr(dy1), None, _ptr(dg1), _ptr(dbe1), _ptr(db1), st))
         del da1
         dw1 = torch.empty_like(w1)
         check(L.sei_conv_backward_weight(rb.h, _ptr(x), _ptr(dy1), _ptr(dw1), None, C, C, st))
@@ -356,12 +357,12 @@ class _ConvBN(torch.autograd.Function):
                                         _ptr(residual), _ptr(a), _ptr(mean), _ptr(invstd), _stream()))
         ctx.rb, ctx.leak, ctx.training = rb, leak, training
         ctx.has_bias, ctx.has_res, ctx.has_affine = b is not None, residual is not None, gamma is not None
-        ctx.save_for_backward(x, y, a, w, gamma, mean, invstd)
+        ctx.save_for_backward(x, y, a, w, gamma, mean, invstd, beta)
         return a
 
     @staticmethod
     def backward(ctx, da):
-        x, y, a, w, gamma, mean, invstd = ctx.saved_tensors
+        x, y, a, w, gamma, mean, invstd, beta = ctx.saved_tensors
         da = _f32c(da)
         rb = ctx.rb
         nIn, nOut = w.shape[1], w.shape[2]
@@ -373,8 +374,10 @@ class _ConvBN(torch.autograd.Function):
         dbe = torch.empty(nOut, dtype=torch.float32, device=dev) if ctx.has_affine else None
         want_db = ctx.has_bias and ctx.needs_input_grad[3]
         db = torch.empty(nOut, dtype=torch.float32, device=dev) if want_db else None
-        check(L.sei_bn_backward_colsum(_ptr(y), _ptr(a), _ptr(da), n, nOut, _ptr(gamma), _ptr(mean), _ptr(invstd), ctx.leak,
-                                       1 if ctx.training else 0, _ptr(dy), _ptr(dres), _ptr(dg), _ptr(dbe), _ptr(db), st))
+        # without a residual the activation mask is recomputed from y (a is not read)
+        check(L.sei_bn_backward_colsum(_ptr(y), _ptr(a) if ctx.has_res else None, _ptr(da), n, nOut, _ptr(gamma), _ptr(beta),
+                                       _ptr(mean), _ptr(invstd), ctx.leak, 1 if ctx.training else 0, _ptr(dy), _ptr(dres),
+                                       _ptr(dg), _ptr(dbe), _ptr(db), st))
         dx = dw = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((rb.n_src, nIn), dtype=torch.float32, device=dev)
