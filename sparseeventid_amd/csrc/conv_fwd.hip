@@ -113,6 +113,8 @@ constexpr int occ_for(int maxs, int nt, int slj) {
     // waves per SIMD the register allocator should aim for (LDS decides the rest):
     // accumulators + saved tile values + two A fragment sets + B values + ~80 registers of addressing / indices
     const int est = maxs * nt * 4 + nt * 4 + 2 * maxs * slj * 4 + nt + 80;
+    // (NT=4, MAXS=2, SLJ=2 lands on 3 waves and spills 5 VGPRs; at 2 waves without the spill it measured 72.6 vs 82.1
+    // TFLOP/s at level 3 of the 64-event batch -- occupancy wins)
     return est <= 132 ? 4 : (est <= 165 ? 3 : (est <= 250 ? 2 : 1));
 }
 
@@ -472,12 +474,13 @@ static ConvPlan plan_tile(int nIn, int nOut, int K, int64_t n_dst) {
             }
         }
         p.slj = (nIn % 32 == 0) ? 2 : 1;
-        if (nOut == 96) {
-            // 96 columns: eight-wave workgroups -- one sub-chunk per wave and offset on 128-row tiles, two column blocks
-            // of 48, 16-plane weight slices: 30 KB of LDS and ~60 VGPRs, four workgroups (32 waves) per CU.  A phase
-            // is one latency chain (barrier -> B from LDS -> MFMA -> LDS add) with little MFMA content; more
-            // independent chains per CU is what raises the MFMA rate: 74.4 vs 69.1 TFLOP/s at level 2 of the
-            // 64-event batch (profiles/r02_conv_units_experiment.log; 128 / 160 columns: +1-2 %, 192: slower).
+        if (nOut == 96 || ((nOut == 128 || nOut == 160) && n_dst >= 100000)) {
+            // 96 / 128 / 160 columns: eight-wave workgroups -- one sub-chunk per wave and offset on 128-row tiles, two
+            // column blocks, 16-plane weight slices: 30-50 KB of LDS and 60-90 VGPRs (no spills), three or four
+            // workgroups (24-32 waves) per CU.  A phase is one latency chain (barrier -> B from LDS -> MFMA -> LDS
+            // add) with little MFMA content; more independent chains per CU is what raises the MFMA rate: 74.4 vs
+            // 69.1 TFLOP/s at 96 columns, 82.7 vs 82.1 at 128, 78.0 vs 76.7 at 160 (64-event batch, one device each;
+            // profiles/r02_conv_units_experiment.log); 192 columns (level 5, few tiles): slower, not used.
             p.nw = 8; p.maxs = 1; p.slj = 1; p.blocks = 2;
         }
         int em, ec, es, eb, ew;
