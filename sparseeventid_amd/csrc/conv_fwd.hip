@@ -367,12 +367,17 @@ __global__ __launch_bounds__(256) void conv_tile_smallcin_kernel(
 #pragma unroll
                 for (int ci = 0; ci < CIN; ci++) xv[q][ci] = X[(size_t)(src >= 0 ? src : 0) * CIN + ci];
             }
+            // rows of one offset are distinct: plain read-modify-write, ALL reads of the sub-chunk before its writes
+            // (written as a chain of `+=` the compiler must assume aliasing and serialises STEPS LDS round trips)
+            float tv[STEPS];
+#pragma unroll
+            for (int q = 0; q < STEPS; q++) tv[q] = acc[dl[q] * COUT + co];
 #pragma unroll
             for (int q = 0; q < STEPS; q++) {
                 float v = 0.f;
 #pragma unroll
                 for (int ci = 0; ci < CIN; ci++) v = fmaf(xv[q][ci], wk[ci], v);
-                if (ok[q]) acc[dl[q] * COUT + co] += v;  // rows of one offset are distinct: plain read-modify-write
+                if (ok[q]) acc[dl[q] * COUT + co] = tv[q] + v;
             }
         }
         __syncthreads();  // offsets are phases: fixed per-row summation order

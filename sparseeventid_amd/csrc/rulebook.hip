@@ -4,6 +4,8 @@
 // ("per-wavefront rulebook segments").
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace sei {
 
 // One thread per (tile, k, row-in-tile): nbr[(tile*K + k)*TR + r] = src row feeding dst row
@@ -53,60 +55,98 @@ __global__ void probe_kernel(const int32_t *__restrict__ dst_coords, int64_t n_d
     }
 }
 
-// One workgroup (TR threads) per tile, thread = dst row.  FILL=false: count sub-chunks per offset and
-// record the tile-relative segment starts.  FILL=true: write the compacted, padded sub-chunks.
+// One workgroup (TR threads = TR/64 waves) per tile.  Every WAVE owns whole offsets (k = wave, wave + nw, ...) and walks
+// the tile's rows of that offset in 64-row chunks, so the compaction needs no workgroup barrier per offset (the former
+// thread-per-row version synchronised K times per tile: 125 times for the stem).
+// FILL=false: count the rules per offset, then one wave turns the counts into tile-relative sub-chunk starts
+// (tile_seg / seg_start).  FILL=true: write the compacted, padded sub-chunks (rules of an offset in dst-row order).
+constexpr int RULE_STRIPES = 128;
+
 template <bool FILL>
 __global__ void tile_rules_kernel(const int32_t *__restrict__ nbr, int K, int TR, int n_tiles,
                                   int32_t *__restrict__ tile_subs, int32_t *__restrict__ tile_seg,
                                   int32_t *__restrict__ seg_start, unsigned long long *__restrict__ totals,
                                   const int32_t *__restrict__ tile_sub_start, int32_t *__restrict__ sub_src,
                                   uint8_t *__restrict__ sub_dst) {
-    __shared__ int wcnt[2][4];
+    extern __shared__ int cnt_k[];  // [K] rules per offset (count pass only)
     const int tile = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nw = TR >> 6;
     const int32_t *nb = nbr + (int64_t)tile * K * TR;
-    int subs = 0, rules = 0;
-    int64_t base_sub = FILL ? tile_sub_start[tile] : 0;
-    for (int k = 0; k < K; k++) {
-        int src = nb[k * TR + threadIdx.x];
-        bool hit = src >= 0;
-        unsigned long long bal = __ballot(hit);
-        if (lane == 0) wcnt[k & 1][wave] = __popcll(bal);
+    if (!FILL) {
+        for (int k = wave; k < K; k += nw) {
+            int c = 0;
+            for (int ch = 0; ch < nw; ch++) c += __popcll(__ballot(nb[k * TR + ch * 64 + lane] >= 0));
+            if (lane == 0) cnt_k[k] = c;
+        }
         __syncthreads();
-        int before = 0, cnt = 0;
-        for (int w = 0; w < nw; w++) {
-            int c = wcnt[k & 1][w];
-            if (w < wave) before += c;
-            cnt += c;
+        if (wave == 0) {
+            int run = 0, rules = 0;
+            for (int k0 = 0; k0 < K; k0 += 64) {
+                const int k = k0 + lane;
+                const int c = k < K ? cnt_k[k] : 0;
+                const int ns = (c + SUB_SLOTS - 1) / SUB_SLOTS;
+                int incl = ns, csum = c;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int v = __shfl_up(incl, d), w = __shfl_up(csum, d);
+                    if (lane >= d) { incl += v; csum += w; }
+                }
+                if (k < K) {
+                    const int start = run + incl - ns;
+                    tile_seg[(int64_t)tile * (K + 1) + k] = start;
+                }
+                run += __shfl(incl, 63);
+                rules += __shfl(csum, 63);
+            }
+            if (lane == 0) {
+                tile_seg[(int64_t)tile * (K + 1) + K] = run;
+                tile_subs[tile] = run;
+                // striped over RULE_STRIPES addresses: ~100 000 tiles per step adding to ONE address serialise at the L2
+                // (the count pass took 180 us per launch, more than the fill pass that writes the rules)
+                atomicAdd(&totals[4 + (tile & (RULE_STRIPES - 1))], (unsigned long long)rules);
+            }
         }
-        int ns = (cnt + SUB_SLOTS - 1) / SUB_SLOTS;
-        if (!FILL) {
-            if (threadIdx.x == 0) {
-                tile_seg[(int64_t)tile * (K + 1) + k] = subs;
-                seg_start[(int64_t)k * n_tiles + tile] = subs;
+    } else {
+        const int64_t base_sub = tile_sub_start[tile];
+        for (int k = wave; k < K; k += nw) {
+            const int64_t slot0 = (base_sub + tile_seg[(int64_t)tile * (K + 1) + k]) * SUB_SLOTS;
+            int run = 0;
+            for (int ch = 0; ch < nw; ch++) {
+                const int src = nb[k * TR + ch * 64 + lane];
+                const bool hit = src >= 0;
+                const unsigned long long bal = __ballot(hit);
+                if (hit) {
+                    const int rank = run + __popcll(bal & ((1ull << lane) - 1ull));
+                    sub_src[slot0 + rank] = src;
+                    sub_dst[slot0 + rank] = (uint8_t)(ch * 64 + lane);
+                }
+                run += __popcll(bal);
             }
-        } else if (cnt > 0) {
-            int64_t slot0 = (base_sub + subs) * SUB_SLOTS;
-            if (hit) {
-                int rank = before + __popcll(bal & ((1ull << lane) - 1ull));
-                sub_src[slot0 + rank] = src;
-                sub_dst[slot0 + rank] = (uint8_t)threadIdx.x;
-            }
-            int pad = ns * SUB_SLOTS - cnt;
-            if ((int)threadIdx.x < pad) {
-                sub_src[slot0 + cnt + threadIdx.x] = -1;
-                sub_dst[slot0 + cnt + threadIdx.x] = 0;
+            const int pad = ((run + SUB_SLOTS - 1) / SUB_SLOTS) * SUB_SLOTS - run;
+            if (lane < pad) {
+                sub_src[slot0 + run + lane] = -1;
+                sub_dst[slot0 + run + lane] = 0;
             }
         }
-        subs += ns;
-        rules += cnt;
     }
-    if (!FILL && threadIdx.x == 0) {
-        tile_seg[(int64_t)tile * (K + 1) + K] = subs;
-        seg_start[(int64_t)K * n_tiles + tile] = subs;
-        tile_subs[tile] = subs;
-        atomicAdd(&totals[0], (unsigned long long)rules);
+}
+
+// seg_start[k][tile] = tile_seg[tile][k]: the k-major copy the dW kernel walks (one k over many tiles).  Written through
+// an LDS tile so that both sides are coalesced (the count pass used to scatter K 4-byte values per tile).
+__global__ __launch_bounds__(256) void transpose_seg_kernel(const int32_t *__restrict__ tile_seg, int32_t *__restrict__ seg_start,
+                                                            int n_tiles, int K1) {
+    __shared__ int t[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int tile0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
+    for (int j = ty; j < 32; j += 8) {
+        const int tile = tile0 + j, k = k0 + tx;
+        if (tile < n_tiles && k < K1) t[j][tx] = tile_seg[(int64_t)tile * K1 + k];
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int k = k0 + j, tile = tile0 + tx;
+        if (tile < n_tiles && k < K1) seg_start[(int64_t)k * n_tiles + tile] = t[tx][j];
     }
 }
 
@@ -141,8 +181,8 @@ static int build_tiled(const int32_t *dst_coords, int64_t n_dst, int64_t n_src, 
     int64_t tot = (int64_t)t.n_tiles * K * tile_rows;
     SEI_TRY(pool_alloc_t(&nbr, tot, st));
     SEI_TRY(pool_alloc_t(&tile_subs, t.n_tiles + 1, st));
-    SEI_TRY(pool_alloc_t(&totals, 4, st));
-    SEI_HIP(hipMemsetAsync(totals, 0, 4 * sizeof(unsigned long long), st));
+    SEI_TRY(pool_alloc_t(&totals, 4 + RULE_STRIPES, st));  // [2] = sub-chunk total (scan), [4..] = striped rule counts
+    SEI_HIP(hipMemsetAsync(totals, 0, (4 + RULE_STRIPES) * sizeof(unsigned long long), st));
     // submanifold: dst level == src level and the filter is odd in every dimension, so rules come in mirrored pairs
     const bool mirror = g.mode == 0 && (g.f0 & 1) && (g.f1 & 1) && (g.f2 & 1) && K > 1;
     const int KP = mirror ? (K + 1) / 2 : K;
@@ -150,20 +190,22 @@ static int build_tiled(const int32_t *dst_coords, int64_t n_dst, int64_t n_src, 
     const int64_t ptot = (int64_t)t.n_tiles * KP * tile_rows;
     probe_kernel<<<(unsigned)((ptot + 255) / 256), 256, 0, st>>>(dst_coords, n_dst, K, KP, tile_rows, t.n_tiles, g,
                                                                 src_ht.keys, src_ht.vals, src_ht.mask, nbr);
-    tile_rules_kernel<false><<<t.n_tiles, tile_rows, 0, st>>>(nbr, K, tile_rows, t.n_tiles, tile_subs, t.tile_seg,
+    tile_rules_kernel<false><<<t.n_tiles, tile_rows, K * sizeof(int), st>>>(nbr, K, tile_rows, t.n_tiles, tile_subs, t.tile_seg,
                                                               t.seg_start, totals, nullptr, nullptr, nullptr);
+    transpose_seg_kernel<<<dim3((t.n_tiles + 31) / 32, (K + 1 + 31) / 32), 256, 0, st>>>(t.tile_seg, t.seg_start, t.n_tiles, K + 1);
     SEI_LAUNCH_CHECK();
     SEI_TRY(exclusive_scan_i32(tile_subs, t.tile_sub_start, t.n_tiles, (int32_t *)(totals + 2), st));
     SEI_HIP(hipMemcpyAsync(t.tile_sub_start + t.n_tiles, totals + 2, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
-    unsigned long long host[3];
-    SEI_HIP(hipMemcpyAsync(host, totals, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    unsigned long long host[4 + RULE_STRIPES];
+    SEI_HIP(hipMemcpyAsync(host, totals, (4 + RULE_STRIPES) * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     SEI_HIP(hipStreamSynchronize(st));
-    t.n_rules = (int64_t)host[0];
+    t.n_rules = 0;
+    for (int i = 0; i < RULE_STRIPES; i++) t.n_rules += (int64_t)host[4 + i];
     t.n_sub = (int64_t)(uint32_t)host[2];
     int64_t ns = t.n_sub > 0 ? t.n_sub : 1;
     SEI_TRY(pool_alloc_t(&t.sub_src, (ns + 1) * SUB_SLOTS, st));  // +1: the kernels' clamped index prefetch may touch the sub-chunk after the last
     SEI_TRY(pool_alloc_t(&t.sub_dst, (ns + 1) * SUB_SLOTS, st));
-    tile_rules_kernel<true><<<t.n_tiles, tile_rows, 0, st>>>(nbr, K, tile_rows, t.n_tiles, nullptr, nullptr, nullptr,
+    tile_rules_kernel<true><<<t.n_tiles, tile_rows, 0, st>>>(nbr, K, tile_rows, t.n_tiles, nullptr, t.tile_seg, nullptr,
                                                              nullptr, t.tile_sub_start, t.sub_src, t.sub_dst);
     SEI_LAUNCH_CHECK();
     pool_free(nbr); pool_free(tile_subs); pool_free(totals);
