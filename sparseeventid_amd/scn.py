@@ -66,8 +66,9 @@ class Metadata:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h is not None and _lib._lib is not None:
-            _lib._lib.sei_metadata_destroy(h)
+        L = getattr(_lib, "_lib", None) if _lib is not None else None   # module globals are None at interpreter exit
+        if h is not None and L is not None:
+            L.sei_metadata_destroy(h)
             self._h = None
 
     @property
