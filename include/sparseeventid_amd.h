@@ -68,6 +68,13 @@ int sei_level_rows(sei_metadata_t *m, const int32_t spatial[3], int64_t *n_rows)
 int sei_level_coords(sei_metadata_t *m, const int32_t spatial[3], int32_t *coords_out_dev, sei_stream_t stream);
 int sei_batch_size(sei_metadata_t *m, int32_t *batch_size);
 
+/* Builds in `m` (which must already hold its input level) every rulebook, and every tiled variant of it, that the
+ * metadata `like` of an EARLIER batch holds -- same filter geometry, this batch's coordinates.  The reference builds
+ * rule books lazily inside the forward pass (SCN Metadata::getSubmanifoldRuleBook / getRuleBook); a training loop that
+ * knows its next batch can call this on a side stream while the current step computes, and the forward then finds
+ * everything built.  Fails like the lazy path would if a level of `like` does not exist for this batch. */
+int sei_metadata_prebuild_like(sei_metadata_t *m, sei_metadata_t *like, sei_stream_t stream);
+
 /* ---- rulebooks (SCN `getSubmanifoldRuleBook` / `getRuleBook`) ---------------------------- */
 /* Cached in the metadata per (spatial, filter).  Synchronises `stream` on first build. */
 int sei_subm_rulebook(sei_metadata_t *m, const int32_t spatial[3], const int32_t filter[3],

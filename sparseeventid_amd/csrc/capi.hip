@@ -314,6 +314,41 @@ int sei_conv_rulebook(sei_metadata_t *m, const int32_t spatial_in[3], const int3
     return 0;
 }
 
+int sei_metadata_prebuild_like(sei_metadata_t *m, sei_metadata_t *like, sei_stream_t stream) {
+    if (!m || !like) SEI_FAIL("sei_metadata_prebuild_like: null argument");
+    if (m == like) return 0;
+    struct Item {
+        bool subm;
+        int32_t sp[3], size[3], stride[3];
+        bool fwd[SEI_NVARIANT], bwd[SEI_NVARIANT];
+    };
+    std::vector<Item> items;
+    {
+        std::lock_guard<std::mutex> lk(like->mu);
+        for (auto *rb : like->rulebooks) {
+            std::lock_guard<std::mutex> lr(rb->mu);
+            Item it;
+            it.subm = rb->submanifold;
+            for (int d = 0; d < 3; d++) { it.sp[d] = rb->spatial_in[d]; it.size[d] = rb->size[d]; it.stride[d] = rb->stride[d]; }
+            for (int v = 0; v < SEI_NVARIANT; v++) { it.fwd[v] = rb->fwd[v].built; it.bwd[v] = rb->bwd[v].built; }
+            items.push_back(it);
+        }
+    }
+    // creation order = the order of the template's forward pass: strided rulebooks create the levels later ones need
+    for (const Item &it : items) {
+        sei_rulebook_t *rb = nullptr;
+        int32_t spo[3];
+        if (it.subm) SEI_TRY(sei_subm_rulebook(m, it.sp, it.size, stream, &rb));
+        else SEI_TRY(sei_conv_rulebook(m, it.sp, it.size, it.stride, stream, &rb, spo));
+        const TiledRules *t;
+        for (int v = 0; v < SEI_NVARIANT; v++) {
+            if (it.fwd[v]) SEI_TRY(get_tiled(rb, false, 64 * (v + 1), &t, (hipStream_t)stream));
+            if (it.bwd[v]) SEI_TRY(get_tiled(rb, true, 64 * (v + 1), &t, (hipStream_t)stream));
+        }
+    }
+    return 0;
+}
+
 int sei_rulebook_info(const sei_rulebook_t *rb_c, int64_t info[8]) {
     sei_rulebook_t *rb = const_cast<sei_rulebook_t *>(rb_c);
     std::lock_guard<std::mutex> lk(rb->mu);

@@ -75,6 +75,14 @@ class Metadata:
     def handle(self):
         return self._h
 
+    def prebuild_like(self, other):
+        """Build, for THIS batch, every rulebook (and tiled variant) the metadata of an earlier batch holds
+        (``sei_metadata_prebuild_like``) on the current stream.  A training loop calls it on a side stream for the next
+        batch while the current step computes; the forward pass then finds its rulebooks built."""
+        if other is None or other is self or other._h is None:
+            return
+        check(lib().sei_metadata_prebuild_like(self._h, other._h, _stream()))
+
     def rows(self, spatial):
         n = ctypes.c_int64()
         check(lib().sei_level_rows(self._h, i32x3(spatial), ctypes.byref(n)))
@@ -563,6 +571,12 @@ class InputLayer(nn.Module):
         self.device = None
 
     def forward(self, input):
+        if isinstance(input, SparseConvNetTensor):
+            # already an input-level tensor (built ahead of time, e.g. Trainer.prefetch on a side stream)
+            if _triple(input.spatial_size) != _triple(self.spatial_size):
+                raise ValueError("InputLayer: prepared tensor has spatial size %r, layer expects %r"
+                                 % (_triple(input.spatial_size), _triple(self.spatial_size)))
+            return input
         coords, features = input[0], input[1]
         batch_size = int(input[2]) if len(input) > 2 and input[2] is not None else None
         dev = features.device if isinstance(features, torch.Tensor) and features.is_cuda else torch.device("cuda")

@@ -41,6 +41,13 @@ class WarmupFlatDecay:
     __call__ = __getitem__
 
 
+class Prefetched:
+    """An input batch whose InputLayer and rulebooks were built ahead of time on a side stream (Trainer.prefetch)."""
+
+    def __init__(self, tensor, event):
+        self.tensor, self.event = tensor, event
+
+
 class Trainer:
     """Owns encoder + heads (reference topology), the flat parameter/gradient arenas and Adam."""
 
@@ -74,6 +81,8 @@ class Trainer:
         self.lr_schedule = lr_schedule or WarmupFlatDecay()
         self.global_step = 0
         self.device = device
+        self._side = None        # stream of Trainer.prefetch
+        self._template = None    # metadata of the last batch that went through forward(): what prefetch() rebuilds
 
     def _build_optimizer(self, start):
         """Adam over arena[start:] as ONE flat tensor == Adam on every parameter in it (elementwise), one fused
@@ -109,7 +118,40 @@ class Trainer:
         lab = {k: torch.as_tensor(v).to(self.device, non_blocking=True) for k, v in labels.items()}
         return (c, f, bs), lab
 
+    def prefetch(self, image):
+        """Builds the NEXT batch's InputLayer hash and every rulebook the last forward pass used, on a side stream,
+        while the current step is still computing (the reference builds them lazily inside the forward pass,
+        resnet.py:141-161 -> SCN Metadata).  Call it right after ``train_step`` returned -- the step's kernels are
+        queued, the rulebook kernels fill the gaps they leave -- and hand the result to the next ``train_step``.
+        Same kernels, same results (every kernel is deterministic); only WHEN the integer work runs changes."""
+        if self.model == "sbnd" or isinstance(image, Prefetched) or not torch.cuda.is_available():
+            return image
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        main = torch.cuda.current_stream()
+        # from here on the side stream may read the input tensors and reuse device-pool blocks that older batches
+        # released: everything that used them was queued on the main stream before this point
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            t = self.encoder.input_layer(image)
+            try:
+                t.metadata.prebuild_like(self._template)
+            except RuntimeError:
+                pass  # a level of the template does not exist for this batch: the forward builds lazily
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+        return Prefetched(t, ev)
+
     def forward(self, image):
+        if self.model != "sbnd":
+            if isinstance(image, Prefetched):
+                main = torch.cuda.current_stream()
+                main.wait_event(image.event)
+                image.tensor.features.record_stream(main)   # allocated on the side stream, consumed here
+                image = image.tensor
+            else:
+                image = self.encoder.input_layer(image)     # Encoder.forward passes a prepared tensor through
+            self._template = image.metadata
         if self.fused_head:
             return self.head.forward_pooled(self.encoder.forward_pooled(image))
         return self.head(self.encoder(image))

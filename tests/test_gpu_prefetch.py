@@ -1,0 +1,99 @@
+"""GPU: rulebooks built ahead of time on a side stream (Trainer.prefetch / sei_metadata_prebuild_like) are the SAME
+rulebooks the forward pass builds lazily (resnet.py:141-161 -> SCN Metadata), and a training loop that prefetches
+every batch ends bit-identical to one that does not (every kernel of the engine is deterministic)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import blob_cloud
+
+pytestmark = pytest.mark.gpu
+HEADS = {"labelneutID": 3, "labelprotID": 3, "labelnpiID": 2, "labelcpiID": 2}
+
+
+def _trainer(seed=3):
+    from sparseeventid_amd.config import Config, Encoder
+    from sparseeventid_amd.train import Trainer
+    cfg = Config(encoder=Encoder(depth=2, n_initial_filters=16, n_output_filters=16, blocks_per_layer=1))
+    return Trainer(cfg=cfg, image_size=[1, 32, 32, 32], output_shape=HEADS, device="cuda", seed=seed)
+
+
+def _batches(tr):
+    out = []
+    for seed, n in ((11, 350), (12, 500), (13, 280)):
+        coords, feats = blob_cloud(seed, 3, [32, 32, 32], n, 1)
+        g = torch.Generator().manual_seed(seed)
+        labels = {k: torch.randint(0, v, (3,), generator=g).numpy() for k, v in HEADS.items()}
+        out.append(tr.stage((coords, feats, 3), labels))
+    return out
+
+
+def test_prebuilt_rulebooks_equal_lazy_rulebooks():
+    import sparseeventid_amd.scn as scn
+    sp = [24, 20, 28]
+    ca, fa = blob_cloud(5, 2, sp, 400, 1)
+    cb, fb = blob_cloud(6, 2, sp, 520, 1)
+    layer = scn.InputLayer(3, sp)
+
+    def walk(t):  # the rulebooks a small network would ask for, built lazily
+        out = []
+        rb = t.metadata.subm_rulebook(sp, [3, 3, 3]); rb.stats(128); out.append(rb)
+        rb = t.metadata.subm_rulebook(sp, [5, 5, 5]); rb.stats(256); out.append(rb)
+        conv = scn.Convolution(3, 16, 16, 2, 2, False).cuda()
+        t.features = torch.randn(t.features.shape[0], 16, device="cuda", requires_grad=True)
+        d = conv(t)
+        d.features.sum().backward()   # builds the transposed variant too
+        sp2 = [int(v) for v in d.spatial_size]
+        rb2 = d.metadata.subm_rulebook(sp2, [3, 3, 3]); rb2.stats(64); out.append(rb2)
+        return out, sp2
+
+    ta = layer((torch.from_numpy(ca), torch.from_numpy(fa).cuda(), 2))
+    walk(ta)
+    # batch B: lazily ...
+    tb_lazy = layer((torch.from_numpy(cb), torch.from_numpy(fb).cuda(), 2))
+    lazy, sp2 = walk(tb_lazy)
+    # ... and prebuilt from A's metadata on a side stream
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        tb_pre = layer((torch.from_numpy(cb), torch.from_numpy(fb).cuda(), 2))
+        tb_pre.metadata.prebuild_like(ta.metadata)
+    torch.cuda.current_stream().wait_stream(side)
+    pre = [tb_pre.metadata.subm_rulebook(sp, [3, 3, 3]), tb_pre.metadata.subm_rulebook(sp, [5, 5, 5]),
+           tb_pre.metadata.subm_rulebook(sp2, [3, 3, 3])]
+    import ctypes
+    from sparseeventid_amd._lib import lib
+    for a, b, tr_rows in zip(lazy, pre, (128, 256, 64)):
+        info = (ctypes.c_int64 * 8)()
+        assert lib().sei_rulebook_info(b.h, info) == 0 and info[7] == tr_rows   # built already, with the template's tile size
+        assert a.n_rules == b.n_rules and a.n_rules > 0
+        sa, ia, oa = a.export("cuda")
+        sb, ib, ob = b.export("cuda")
+        assert list(sa) == list(sb) and torch.equal(ia, ib) and torch.equal(oa, ob)
+
+
+def test_training_with_prefetch_is_bit_identical_to_lazy_training():
+    lazy, pre = _trainer(), _trainer()
+    assert torch.equal(lazy.arena.flat, pre.arena.flat)
+    batches = _batches(lazy)
+    order = [0, 1, 2, 0, 1]
+    losses_lazy = []
+    torch.manual_seed(123)   # the heads hold nn.Dropout: both runs must draw the same masks
+    for i in order:
+        loss, _ = lazy.train_step(*batches[i])
+        losses_lazy.append(float(loss))
+    from sparseeventid_amd.train import Prefetched
+    losses_pre = []
+    torch.manual_seed(123)
+    staged = pre.prefetch(batches[order[0]][0])
+    assert isinstance(staged, Prefetched)
+    for j, i in enumerate(order):
+        loss, _ = pre.train_step(staged, batches[i][1])
+        if j + 1 < len(order):
+            staged = pre.prefetch(batches[order[j + 1]][0])   # while step j is still running
+        losses_pre.append(float(loss))
+    torch.cuda.synchronize()
+    assert losses_lazy == losses_pre
+    assert torch.equal(lazy.arena.flat, pre.arena.flat)
+    for (k, a), (_, b) in zip(lazy.encoder.named_buffers(), pre.encoder.named_buffers()):
+        assert torch.equal(a, b), k
