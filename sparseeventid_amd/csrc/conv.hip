@@ -176,8 +176,18 @@ __device__ __forceinline__ DwOps<MT, NT> dw_load_ops(const DwItem &it, int q, in
     const bool ok = src >= 0;
     // row address = base + u32 row * u32 stride: ONE v_mad_u64_u32 per operand (signed 64-bit index math costs four)
     const uint32_t xr = ok ? (uint32_t)src : 0u, yr = ok ? (uint32_t)drow : 0u;
+#if defined(SEI_DW_ABL_NOGATHER)  // diagnostic: no operand gathers (results are wrong, timing only)
+#pragma unroll
+    for (int m = 0; m < MT; m++) o.a[m] = ok ? 1.f + xr : 0.f;
+#pragma unroll
+    for (int n = 0; n < NT; n++) o.b[n] = ok ? 2.f + yr : 0.f;
+#elif defined(SEI_DW_ABL_CACHED)   // diagnostic: every gather hits the caches
+    dw_load_vec<MT>(X + ci0 + (uint64_t)(xr & 1023u) * (uint32_t)CIN, r16, ok, o.a);
+    dw_load_vec<NT>(dY + (uint64_t)(yr & 1023u) * (uint32_t)COUT, r16, ok, o.b);
+#else
     dw_load_vec<MT>(X + ci0 + (uint64_t)xr * (uint32_t)CIN, r16, ok, o.a);
     dw_load_vec<NT>(dY + (uint64_t)yr * (uint32_t)COUT, r16, ok, o.b);
+#endif
     o.any = __any(ok);
     return o;
 }
@@ -226,7 +236,13 @@ __global__ __launch_bounds__(256) void conv_dw_mfma_kernel(
 #pragma unroll
                         for (int m = 0; m < MT; m++)
 #pragma unroll
-                            for (int n = 0; n < NT; n++) acc[m][n] = mfma16(oc.a[m], oc.b[n], acc[m][n]);
+                            for (int n = 0; n < NT; n++) {
+#ifdef SEI_DW_ABL_NOMFMA  // diagnostic: one VALU fma instead of the MFMA (keeps the operand dependencies)
+                                acc[m][n][0] = fmaf(oc.a[m], oc.b[n], acc[m][n][0]);
+#else
+                                acc[m][n] = mfma16(oc.a[m], oc.b[n], acc[m][n]);
+#endif
+                            }
                     }
                     oc = on;
                 }
