@@ -206,6 +206,45 @@ def test_batchnorm_fused_forward_backward(C, leak, with_res):
     assert rel_err(ye, ze) < TOL
 
 
+@pytest.mark.parametrize("C,n,leak", [(32, 3001, 1 / 3), (96, 70001, 1 / 3), (7, 515, 0.0), (160, 9000, 1.0)])
+def test_bn_backward_colsum_and_recomputed_mask(C, n, leak):
+    """`sei_bn_backward_colsum` through the C ABI: (i) the column sums of dx it emits equal dx.sum(0) (the conv bias
+    gradient), (ii) with y = NULL (no residual) the LeakyReLU mask recomputed from x, gamma, beta gives the SAME dx,
+    dgamma, dbeta as with the stored activation -- bit for bit (same expression as the forward)."""
+    import ctypes
+    from sparseeventid_amd._lib import lib, check
+    scn = _engine()
+    gen = torch.Generator().manual_seed(21)
+    x = (torch.randn(n, C, generator=gen) * 1.7 - 0.3).cuda()
+    g = torch.randn(n, C, generator=gen).cuda()
+    bn = scn.BatchNormalization(C).cuda()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_()
+    y = bn.forward_features(x, leak=leak)
+    mean, var = x.double().mean(0), x.double().var(0, unbiased=False)
+    save_mean = mean.float().contiguous()
+    save_invstd = (1.0 / torch.sqrt(var + bn.eps)).float().contiguous()
+    P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    outs = []
+    for y_arg in (y, None):
+        dx, dg, db, cs = torch.empty_like(x), torch.empty(C, device="cuda"), torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+        check(lib().sei_bn_backward_colsum(P(x), P(y_arg), P(g), n, C, P(bn.weight), P(bn.bias), P(save_mean), P(save_invstd),
+                                           leak, 1, P(dx), None, P(dg), P(db), P(cs), st))
+        outs.append((dx, dg, db, cs))
+    (dx0, dg0, db0, cs0), (dx1, dg1, db1, cs1) = outs
+    assert torch.equal(dx0, dx1) and torch.equal(dg0, dg1) and torch.equal(db0, db1) and torch.equal(cs0, cs1)
+    ref = dx0.double().sum(0)
+    scale = float(dx0.double().abs().sum(0).max())
+    assert float((cs0.double() - ref).abs().max()) < 1e-6 * scale
+    # and the gradient itself against autograd of the same expression in fp64
+    xd = x.double().requires_grad_(True)
+    z = (xd - xd.mean(0)) / torch.sqrt(xd.var(0, unbiased=False) + bn.eps) * bn.weight.double() + bn.bias.double()
+    torch.where(z > 0, z, z * leak).backward(g.double())
+    assert rel_err(dx0, xd.grad) < TOL
+
+
 def test_elementwise_and_dense():
     scn = _engine()
     sp, B, C = [6, 5, 7], 3, 8
