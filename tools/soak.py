@@ -5,6 +5,7 @@ import ctypes, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import generate_batch
 B, STEPS = int(sys.argv[1]) if len(sys.argv) > 1 else 16, int(sys.argv[2]) if len(sys.argv) > 2 else 24
+PREFETCH = len(sys.argv) > 3 and sys.argv[3] == "prefetch"   # tools/soak.py 16 24 prefetch: rulebooks of step i+1 on a side stream
 batches = [generate_batch(0, i, B, (900, 900, 900), 50000 - 3000 * (i % 4), "tracks", 16) for i in range(6)]
 import torch
 from sparseeventid_amd import _lib
@@ -13,10 +14,13 @@ tr = Trainer(image_size=[1, 900, 900, 900])
 lib = _lib.lib()
 held, used = ctypes.c_int64(), ctypes.c_int64()
 t0 = time.time()
+staged_in = [tr.stage(tr.to_scn_input(arr), labels) for arr, labels in batches]
+nxt = tr.prefetch(staged_in[0][0]) if PREFETCH else None
 for step in range(STEPS):
-    arr, labels = batches[step % len(batches)]
-    image, lab = tr.stage(tr.to_scn_input(arr), labels)
-    loss, _ = tr.train_step(image, lab)
+    image, lab = staged_in[step % len(batches)]
+    loss, _ = tr.train_step(nxt if PREFETCH else image, lab)
+    if PREFETCH:
+        nxt = tr.prefetch(staged_in[(step + 1) % len(batches)][0])
     if step % 4 == 3 or step == STEPS - 1:
         torch.cuda.synchronize()
         lib.sei_pool_stats(ctypes.byref(held), ctypes.byref(used))
