@@ -137,12 +137,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : occ_for(MAXS, NT, SLJ))) vo
     constexpr int COUT = NC * CS;
     constexpr int PIECES = SL * COUT / 256;  // 1-KiB LDS-DMA pieces per weight slice (contiguous in W)
     constexpr int ASTRIDE = COUT + APAD;     // accumulator row stride (floats)
-    // workgroups are dealt round-robin to the 8 XCDs: give every XCD one contiguous run of tiles so that
-    // neighbouring tiles (which gather many of the same src rows) share that XCD's L2 (speed only)
-    // (blocks > 1: the COUT columns handled here are one of `blocks` column blocks of the ldy-wide output; the
-    // blocks of a tile are neighbours in this order, they gather the same src rows)
-    const int per_xcd = (n_tiles * blocks + 7) >> 3;
-    const int vid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    // work item = (tile, column block), XCD-aware order (xcd_item, conv_tile.h): neighbouring tiles -- which gather many
+    // of the same src rows -- and the column blocks of a tile -- which gather exactly the same ones -- run on one XCD
+    // and share its L2 (speed only)
+    const int vid = xcd_item(n_tiles * blocks);
     if (vid >= n_tiles * blocks) return;
     const int tile = vid / blocks, cblk = vid - tile * blocks;
     W += (size_t)cblk * K * CIN * COUT;

@@ -8,6 +8,24 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ inline f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
+// Workgroup id -> work item for kernels whose consecutive items share gathered rows.  Workgroups are dealt round-robin
+// to the 8 XCDs (blockIdx & 7); every XCD gets CONTIGUOUS runs of XCD_CHUNK items, the runs dealt round-robin to the XCDs:
+// neighbours inside a run share that XCD's L2, and every XCD samples all of the batch's events, so they finish together
+// (one run per XCD -- round 1's mapping -- leaves them with unequal work when the events differ).  Measured on the
+// 64-event step, two devices: runs of 4-16 items 368.8 / 366.5 ms, one run per XCD 370.8 / 368.0, runs of 1 = plain
+// round-robin 371.2, runs of 256 370.2 (tools/bench_ab.sh).  `total` items, grid = 8 * ceil(total / 8) workgroups.
+#ifndef SEI_XCD_CHUNK
+#define SEI_XCD_CHUNK 16
+#endif
+__device__ inline int xcd_item(int total) {
+    const int x = blockIdx.x & 7, i = blockIdx.x >> 3, per = (total + 7) >> 3;
+    constexpr int CH = SEI_XCD_CHUNK;
+    const int full = per / CH;  // complete rounds of 8 runs
+    if (i < full * CH) return ((i / CH) * 8 + x) * CH + i % CH;
+    const int rem = per - full * CH;  // the tail: one shorter run per XCD
+    return full * CH * 8 + x * rem + (i - full * CH);
+}
+
 // unconditional load (clamped row) + select: conditional loads make hipcc serialise them with vmcnt(0)
 __device__ inline float4 load_a(const float *__restrict__ X, int src, int CIN, int off) {
     int row = src > 0 ? src : 0;

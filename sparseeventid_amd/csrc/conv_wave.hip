@@ -22,6 +22,7 @@
 // padding of 64-row tiles alone, 0.46 / 0.73 / 0.82 / 0.84 (tools/structure_stats.py): waves never wait for each
 // other, and the per-phase barrier, zero-init and weight-staging costs are gone.
 #include "common.h"
+#include "conv_tile.h"
 
 #include <stdlib.h>
 #include <string.h>
@@ -270,12 +271,10 @@ __global__ __launch_bounds__(64, wave_occ(NT, G)) void conv_wave_mfma_kernel(
     const float *__restrict__ init, int ldy, int blocks, int TR, double *__restrict__ stats) {
     extern __shared__ float lds[];
     constexpr int NC = 16 * NT;  // columns of this wave = LDS row stride
-    // workgroups (= waves) are dealt round-robin to the 8 XCDs: give every XCD one contiguous run of tiles so that
-    // neighbouring tiles (which gather many of the same src rows) share that XCD's L2; the column blocks of a tile
-    // are neighbours in this order (speed only)
+    // work item = (tile, column block) in the XCD-aware order of xcd_item (conv_tile.h): neighbouring tiles and the column
+    // blocks of a tile share an XCD's L2 (speed only)
     const int nwork = n_tiles * blocks;
-    const int per_xcd = (nwork + 7) >> 3;
-    const int vid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const int vid = xcd_item(nwork);
     if (vid >= nwork) return;
     const int tile = vid / blocks, cblk = vid - tile * blocks;
     const int col0 = cblk * NC;
