@@ -6,7 +6,10 @@
 
 namespace sei {
 
-constexpr int RED_BLOCKS_MAX = 1024;
+#ifndef SEI_RED_BLOCKS_MAX
+#define SEI_RED_BLOCKS_MAX 1024
+#endif
+constexpr int RED_BLOCKS_MAX = SEI_RED_BLOCKS_MAX;
 
 // ------------------------------------------------------------------ column reductions
 // MODE 0: (x, x*x)                         -> BN statistics
@@ -336,7 +339,10 @@ __global__ void eval_stats_kernel(const float *rmean, const float *rvar, float e
 
 static inline unsigned ew_blocks(int64_t total_vec) {
     int64_t b = (total_vec + 255) / 256;
-    return (unsigned)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
+#ifndef SEI_EW_BLOCKS_MAX
+#define SEI_EW_BLOCKS_MAX 8192
+#endif
+    return (unsigned)(b > SEI_EW_BLOCKS_MAX ? SEI_EW_BLOCKS_MAX : (b < 1 ? 1 : b));
 }
 
 // grid for the per-channel kernels: a multiple of m = C / gcd(C, 256*vec) blocks, so that the grid stride (in
