@@ -199,7 +199,7 @@ int larcv_compact(const float *in, int B, int P, int M, int D, int32_t *coords, 
 inline int variant_of(int tile_rows) { return tile_rows / 64 - 1; }
 // returns the (lazily built) tiled rules of the rulebook: transposed=false -> fwd, true -> bwd
 int get_tiled(sei_rulebook *rb, bool transposed, int tile_rows, const TiledRules **out, hipStream_t st);
-// any already-built variant (prefers 256 rows), building the 256 one if none exists
+// any already-built variant (the smallest tile size first), building the 128-row one if none exists
 int get_any_tiled(sei_rulebook *rb, bool transposed, const TiledRules **out, hipStream_t st);
 int build_strided_level(sei_metadata *m, Level *lin, const int32_t size[3], const int32_t stride[3], sei_rulebook *rb,
                         hipStream_t st);
