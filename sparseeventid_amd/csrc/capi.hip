@@ -196,6 +196,8 @@ void sei_metadata_destroy(sei_metadata_t *m) {
             free_tiled(rb->fwd[v]);
             free_tiled(rb->bwd[v]);
         }
+        pool_free(rb->nbr_fwd);
+        pool_free(rb->nbr_bwd);
         delete rb;
     }
     for (auto *l : m->levels) free_level(l);
@@ -500,7 +502,10 @@ int sei_conv_backward_weight(sei_rulebook_t *rb, const float *X, const float *dY
     if (!rb) SEI_FAIL("null rulebook");
     hipStream_t st = (hipStream_t)stream;
     const TiledRules *t;
-    SEI_TRY(get_any_tiled(rb, false, &t, st));
+    // dW contracts over rule SLOTS, so padding slots are wasted MFMA steps: it walks the 256-row variant (pads to 0.93 where
+    // the forward kernels' 64- / 128-row tiles pad to 0.73 / 0.90), cut from the rulebook's cached neighbour table (no second
+    // probe): conv_bwd_weight 96.9 -> 93.6 ms per step for ~0.7 ms of extra tiling
+    SEI_TRY(get_tiled(rb, false, 256, &t, st));
     {
         ProfScope ps(PROF_CONV_BWD_W, st, 2.0 * t->n_rules * nIn * nOut,
                      4.0 * t->n_src * nIn + 4.0 * t->n_dst * nOut + 8.0 * t->n_rules + 4.0 * t->K * nIn * nOut);

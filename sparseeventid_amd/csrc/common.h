@@ -163,6 +163,7 @@ constexpr int SEI_NVARIANT = 4;  // tile_rows 64 / 128 / 192 / 256
 struct sei_rulebook {
     sei::TiledRules fwd[SEI_NVARIANT];  // dst = output rows, src = input rows
     sei::TiledRules bwd[SEI_NVARIANT];  // dst = input rows,  src = output rows (strided conv only)
+    int32_t *nbr_fwd = nullptr, *nbr_bwd = nullptr;  // k-major neighbour tables [K][n_dst], kept for later tiled variants
     bool submanifold = true;            // bwd == fwd with mirrored k
     int32_t spatial_in[3], spatial_out[3], size[3], stride[3];
     sei::Level *lin = nullptr, *lout = nullptr;

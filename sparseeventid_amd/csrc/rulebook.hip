@@ -8,25 +8,24 @@
 
 namespace sei {
 
-// One thread per (tile, k, row-in-tile): nbr[(tile*K + k)*TR + r] = src row feeding dst row
-// tile*TR + r through offset k, or -1.  Consecutive lanes = consecutive dst rows, same offset:
-// coalesced coord reads / nbr writes, and the probed keys are spatial neighbours of each other.
+// One thread per (k, dst row): nbr[k * n_dst + row] = src row feeding dst row `row` through offset k, or -1 (k-major:
+// independent of any tile size, so every tiled variant of a rulebook is cut from ONE probe).  Consecutive lanes =
+// consecutive dst rows, same offset: coalesced coord reads / nbr writes, and the probed keys are
+// spatial neighbours of each other.
 // KP = offsets actually probed.  Submanifold rulebooks (mode 0, odd filter) probe only the first half of the
 // offsets plus the centre: a hit (i -> o) at offset k is also the rule (o -> i) at the mirrored offset K-1-k, so
 // it is written to both places (the table is preset to -1) -- half the hash probes, which dominate this kernel
 // (92 % of the stem's 125 probes per site are misses).
-__global__ void probe_kernel(const int32_t *__restrict__ dst_coords, int64_t n_dst, int K, int KP, int TR, int n_tiles,
-                             ProbeGeom g, const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals,
-                             uint64_t mask, int32_t *__restrict__ nbr) {
-    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (int64_t)n_tiles * KP * TR) return;
-    int r = (int)(t % TR);
-    int64_t tk = t / TR;
-    int k = (int)(tk % KP);
-    const int64_t tile = tk / KP;
-    int64_t row = tile * TR + r;
+__global__ void probe_kernel(const int32_t *__restrict__ dst_coords, int64_t n_dst, int K, int KP, ProbeGeom g,
+                             const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, uint64_t mask,
+                             int32_t *__restrict__ nbr) {
+    // workgroup b = (row chunk b / KP, offset b % KP): consecutive workgroups probe the SAME 256 sites under consecutive
+    // offsets, so their hash-table lines are still warm (one offset over all sites, then the next, measured 12 % slower)
+    const int k = (int)(blockIdx.x % (unsigned)KP);
+    const int64_t row = (int64_t)(blockIdx.x / (unsigned)KP) * blockDim.x + threadIdx.x;
+    if (row >= n_dst) return;
     int res = -1;
-    if (row < n_dst) {
+    {
         int4 c = reinterpret_cast<const int4 *>(dst_coords)[row];
         int a = k / (g.f1 * g.f2), rem = k - a * (g.f1 * g.f2);
         int b = rem / g.f2, d = rem - b * g.f2;
@@ -45,25 +44,18 @@ __global__ void probe_kernel(const int32_t *__restrict__ dst_coords, int64_t n_d
         if (ok) res = hash_find(keys, vals, mask, pack_key(q0, q1, q2, c.w));
     }
     if (KP == K) {
-        nbr[(tile * K + k) * TR + r] = res;
+        nbr[(int64_t)k * n_dst + row] = res;
     } else if (res >= 0) {
-        nbr[(tile * K + k) * TR + r] = res;
-        if (k != K - 1 - k) {  // mirrored rule: dst row `res` receives from `row` through offset K-1-k
-            const int64_t mt = res / TR;
-            nbr[(mt * K + (K - 1 - k)) * TR + (res - mt * TR)] = (int32_t)row;
-        }
+        nbr[(int64_t)k * n_dst + row] = res;
+        if (k != K - 1 - k)  // mirrored rule: dst row `res` receives from `row` through offset K-1-k
+            nbr[(int64_t)(K - 1 - k) * n_dst + res] = (int32_t)row;
     }
 }
 
-// One workgroup (TR threads = TR/64 waves) per tile.  Every WAVE owns whole offsets (k = wave, wave + nw, ...) and walks
-// the tile's rows of that offset in 64-row chunks, so the compaction needs no workgroup barrier per offset (the former
-// thread-per-row version synchronised K times per tile: 125 times for the stem).
-// FILL=false: count the rules per offset, then one wave turns the counts into tile-relative sub-chunk starts
-// (tile_seg / seg_start).  FILL=true: write the compacted, padded sub-chunks (rules of an offset in dst-row order).
 constexpr int RULE_STRIPES = 128;
 
 template <bool FILL>
-__global__ void tile_rules_kernel(const int32_t *__restrict__ nbr, int K, int TR, int n_tiles,
+__global__ void tile_rules_kernel(const int32_t *__restrict__ nbr, int64_t n_dst, int K, int TR, int n_tiles,
                                   int32_t *__restrict__ tile_subs, int32_t *__restrict__ tile_seg,
                                   int32_t *__restrict__ seg_start, unsigned long long *__restrict__ totals,
                                   const int32_t *__restrict__ tile_sub_start, int32_t *__restrict__ sub_src,
@@ -72,11 +64,14 @@ __global__ void tile_rules_kernel(const int32_t *__restrict__ nbr, int K, int TR
     const int tile = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nw = TR >> 6;
-    const int32_t *nb = nbr + (int64_t)tile * K * TR;
+    const int64_t row0 = (int64_t)tile * TR;
+    auto nb_at = [&](int k, int r) {  // neighbour of tile row r under offset k (-1 beyond the last row)
+        return row0 + r < n_dst ? nbr[(int64_t)k * n_dst + row0 + r] : -1;
+    };
     if (!FILL) {
         for (int k = wave; k < K; k += nw) {
             int c = 0;
-            for (int ch = 0; ch < nw; ch++) c += __popcll(__ballot(nb[k * TR + ch * 64 + lane] >= 0));
+            for (int ch = 0; ch < nw; ch++) c += __popcll(__ballot(nb_at(k, ch * 64 + lane) >= 0));
             if (lane == 0) cnt_k[k] = c;
         }
         __syncthreads();
@@ -113,7 +108,7 @@ __global__ void tile_rules_kernel(const int32_t *__restrict__ nbr, int K, int TR
             const int64_t slot0 = (base_sub + tile_seg[(int64_t)tile * (K + 1) + k]) * SUB_SLOTS;
             int run = 0;
             for (int ch = 0; ch < nw; ch++) {
-                const int src = nb[k * TR + ch * 64 + lane];
+                const int src = nb_at(k, ch * 64 + lane);
                 const bool hit = src >= 0;
                 const unsigned long long bal = __ballot(hit);
                 if (hit) {
@@ -156,9 +151,11 @@ void free_tiled(TiledRules &t) {
     t = TiledRules();
 }
 
-// dst rows [n_dst] with coords dst_coords probe the src-level hash; result in *out.
+// dst rows [n_dst] with coords dst_coords probe the src-level hash; result in *out.  *nbr_cache: the rulebook's k-major
+// neighbour table, probed by the first variant that is built and kept for the later ones (dW cuts its own 256-row
+// variant from it) until the rulebook is destroyed.
 static int build_tiled(const int32_t *dst_coords, int64_t n_dst, int64_t n_src, const HashTable &src_ht, int K,
-                       ProbeGeom g, int tile_rows, TiledRules *out, hipStream_t st) {
+                       ProbeGeom g, int tile_rows, TiledRules *out, int32_t **nbr_cache, hipStream_t st) {
     if (K > 4096) SEI_FAIL("rulebook: filter volume too large");
     TiledRules t;
     t.n_dst = n_dst; t.n_src = n_src; t.K = K; t.tile_rows = tile_rows;
@@ -176,22 +173,30 @@ static int build_tiled(const int32_t *dst_coords, int64_t n_dst, int64_t n_src, 
     }
     double bytes = 12.0 * n_dst + 8.0 * K * n_dst;
     ProfScope ps(PROF_RULES, st, 0.0, bytes);
-    int32_t *nbr, *tile_subs;
+    int32_t *tile_subs;
     unsigned long long *totals;
-    int64_t tot = (int64_t)t.n_tiles * K * tile_rows;
-    SEI_TRY(pool_alloc_t(&nbr, tot, st));
     SEI_TRY(pool_alloc_t(&tile_subs, t.n_tiles + 1, st));
     SEI_TRY(pool_alloc_t(&totals, 4 + RULE_STRIPES, st));  // [2] = sub-chunk total (scan), [4..] = striped rule counts
     SEI_HIP(hipMemsetAsync(totals, 0, (4 + RULE_STRIPES) * sizeof(unsigned long long), st));
-    // submanifold: dst level == src level and the filter is odd in every dimension, so rules come in mirrored pairs
-    const bool mirror = g.mode == 0 && (g.f0 & 1) && (g.f1 & 1) && (g.f2 & 1) && K > 1;
-    const int KP = mirror ? (K + 1) / 2 : K;
-    if (mirror) SEI_HIP(hipMemsetAsync(nbr, 0xFF, (size_t)tot * sizeof(int32_t), st));
-    const int64_t ptot = (int64_t)t.n_tiles * KP * tile_rows;
-    probe_kernel<<<(unsigned)((ptot + 255) / 256), 256, 0, st>>>(dst_coords, n_dst, K, KP, tile_rows, t.n_tiles, g,
-                                                                src_ht.keys, src_ht.vals, src_ht.mask, nbr);
-    tile_rules_kernel<false><<<t.n_tiles, tile_rows, K * sizeof(int), st>>>(nbr, K, tile_rows, t.n_tiles, tile_subs, t.tile_seg,
-                                                              t.seg_start, totals, nullptr, nullptr, nullptr);
+    if (!*nbr_cache) {
+        int32_t *nbr;
+        const int64_t tot = (int64_t)K * n_dst;
+        SEI_TRY(pool_alloc_t(&nbr, tot, st));
+        // submanifold: dst level == src level and the filter is odd in every dimension, so rules come in mirrored pairs
+        const bool mirror = g.mode == 0 && (g.f0 & 1) && (g.f1 & 1) && (g.f2 & 1) && K > 1;
+        const int KP = mirror ? (K + 1) / 2 : K;
+        if (mirror) SEI_HIP(hipMemsetAsync(nbr, 0xFF, (size_t)tot * sizeof(int32_t), st));
+        const int64_t chunks = (n_dst + 255) / 256;
+        if (chunks * KP >= (1ll << 31)) SEI_FAIL("rulebook: too many (site, offset) pairs for one launch");
+        probe_kernel<<<(unsigned)(chunks * KP), 256, 0, st>>>(dst_coords, n_dst, K, KP, g, src_ht.keys, src_ht.vals,
+                                                             src_ht.mask, nbr);
+        SEI_LAUNCH_CHECK();
+        *nbr_cache = nbr;
+    }
+    const int32_t *nbr = *nbr_cache;
+    tile_rules_kernel<false><<<t.n_tiles, tile_rows, K * sizeof(int), st>>>(nbr, n_dst, K, tile_rows, t.n_tiles, tile_subs,
+                                                                            t.tile_seg, t.seg_start, totals, nullptr, nullptr,
+                                                                            nullptr);
     transpose_seg_kernel<<<dim3((t.n_tiles + 31) / 32, (K + 1 + 31) / 32), 256, 0, st>>>(t.tile_seg, t.seg_start, t.n_tiles, K + 1);
     SEI_LAUNCH_CHECK();
     SEI_TRY(exclusive_scan_i32(tile_subs, t.tile_sub_start, t.n_tiles, (int32_t *)(totals + 2), st));
@@ -205,10 +210,10 @@ static int build_tiled(const int32_t *dst_coords, int64_t n_dst, int64_t n_src, 
     int64_t ns = t.n_sub > 0 ? t.n_sub : 1;
     SEI_TRY(pool_alloc_t(&t.sub_src, (ns + 1) * SUB_SLOTS, st));  // +1: the kernels' clamped index prefetch may touch the sub-chunk after the last
     SEI_TRY(pool_alloc_t(&t.sub_dst, (ns + 1) * SUB_SLOTS, st));
-    tile_rules_kernel<true><<<t.n_tiles, tile_rows, 0, st>>>(nbr, K, tile_rows, t.n_tiles, nullptr, t.tile_seg, nullptr,
+    tile_rules_kernel<true><<<t.n_tiles, tile_rows, 0, st>>>(nbr, n_dst, K, tile_rows, t.n_tiles, nullptr, t.tile_seg, nullptr,
                                                              nullptr, t.tile_sub_start, t.sub_src, t.sub_dst);
     SEI_LAUNCH_CHECK();
-    pool_free(nbr); pool_free(tile_subs); pool_free(totals);
+    pool_free(tile_subs); pool_free(totals);
     t.built = true;
     *out = t;
     return 0;
@@ -225,12 +230,12 @@ int get_tiled(sei_rulebook *rb, bool transposed, int tile_rows, const TiledRules
                     rb->stride[2], rb->lin->spatial[0], rb->lin->spatial[1], rb->lin->spatial[2]};
         if (!transposed) {
             // dst = output sites probing the input-level hash
-            SEI_TRY(build_tiled(rb->lout->coords, rb->lout->n, rb->lin->n, rb->lin->ht, K, g, tile_rows, &t, st));
+            SEI_TRY(build_tiled(rb->lout->coords, rb->lout->n, rb->lin->n, rb->lin->ht, K, g, tile_rows, &t, &rb->nbr_fwd, st));
         } else {
             // dst = input sites probing the output-level hash
             g.mode = 2;
             g.s0 = rb->lout->spatial[0]; g.s1 = rb->lout->spatial[1]; g.s2 = rb->lout->spatial[2];
-            SEI_TRY(build_tiled(rb->lin->coords, rb->lin->n, rb->lout->n, rb->lout->ht, K, g, tile_rows, &t, st));
+            SEI_TRY(build_tiled(rb->lin->coords, rb->lin->n, rb->lout->n, rb->lout->ht, K, g, tile_rows, &t, &rb->nbr_bwd, st));
         }
     }
     *out = &t;
