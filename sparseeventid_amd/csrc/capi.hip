@@ -282,6 +282,13 @@ int sei_subm_rulebook(sei_metadata_t *m, const int32_t spatial[3], const int32_t
         rb->stride[d] = 1;
     }
     rb->lin = rb->lout = l;  // tiled rule lists are built lazily, per tile size the kernels ask for
+    // a larger odd filter on the same level (the 5^3 stem next to the 3^3 blocks of level 0) already probes every offset
+    // of this one: the tiled lists are then cut from ITS neighbour table, no second probe
+    for (auto *o : m->rulebooks)
+        if (o->submanifold && o->lin == l && o->size[0] >= filter[0] && o->size[1] >= filter[1] && o->size[2] >= filter[2]) {
+            rb->donor = o;
+            break;
+        }
     m->rulebooks.push_back(rb);
     *rb_out = rb;
     return 0;

@@ -164,6 +164,7 @@ struct sei_rulebook {
     sei::TiledRules fwd[SEI_NVARIANT];  // dst = output rows, src = input rows
     sei::TiledRules bwd[SEI_NVARIANT];  // dst = input rows,  src = output rows (strided conv only)
     int32_t *nbr_fwd = nullptr, *nbr_bwd = nullptr;  // k-major neighbour tables [K][n_dst], kept for later tiled variants
+    sei_rulebook *donor = nullptr;      // submanifold rulebook of the SAME level with a larger odd filter: its table contains ours
     bool submanifold = true;            // bwd == fwd with mirrored k
     int32_t spatial_in[3], spatial_out[3], size[3], stride[3];
     sei::Level *lin = nullptr, *lout = nullptr;

@@ -52,10 +52,21 @@ __global__ void probe_kernel(const int32_t *__restrict__ dst_coords, int64_t n_d
     }
 }
 
+// Offsets of a filter (f0,f1,f2) inside the neighbour table of a filter (F0,F1,F2) >= it, both odd and centred
+// (identity when they are equal).
+struct NbrView {
+    int f0, f1, f2, F0, F1, F2;
+    __host__ __device__ int table_k(int k) const {
+        if (f0 == F0 && f1 == F1 && f2 == F2) return k;
+        const int a = k / (f1 * f2), r = k - a * (f1 * f2), b = r / f2, d = r - b * f2;
+        return ((a + (F0 - f0) / 2) * F1 + (b + (F1 - f1) / 2)) * F2 + (d + (F2 - f2) / 2);
+    }
+};
+
 constexpr int RULE_STRIPES = 128;
 
 template <bool FILL>
-__global__ void tile_rules_kernel(const int32_t *__restrict__ nbr, int64_t n_dst, int K, int TR, int n_tiles,
+__global__ void tile_rules_kernel(const int32_t *__restrict__ nbr, NbrView vw, int64_t n_dst, int K, int TR, int n_tiles,
                                   int32_t *__restrict__ tile_subs, int32_t *__restrict__ tile_seg,
                                   int32_t *__restrict__ seg_start, unsigned long long *__restrict__ totals,
                                   const int32_t *__restrict__ tile_sub_start, int32_t *__restrict__ sub_src,
@@ -66,7 +77,7 @@ __global__ void tile_rules_kernel(const int32_t *__restrict__ nbr, int64_t n_dst
     const int nw = TR >> 6;
     const int64_t row0 = (int64_t)tile * TR;
     auto nb_at = [&](int k, int r) {  // neighbour of tile row r under offset k (-1 beyond the last row)
-        return row0 + r < n_dst ? nbr[(int64_t)k * n_dst + row0 + r] : -1;
+        return row0 + r < n_dst ? nbr[(int64_t)vw.table_k(k) * n_dst + row0 + r] : -1;
     };
     if (!FILL) {
         for (int k = wave; k < K; k += nw) {
@@ -155,7 +166,8 @@ void free_tiled(TiledRules &t) {
 // neighbour table, probed by the first variant that is built and kept for the later ones (dW cuts its own 256-row
 // variant from it) until the rulebook is destroyed.
 static int build_tiled(const int32_t *dst_coords, int64_t n_dst, int64_t n_src, const HashTable &src_ht, int K,
-                       ProbeGeom g, int tile_rows, TiledRules *out, int32_t **nbr_cache, hipStream_t st) {
+                       ProbeGeom g, int tile_rows, TiledRules *out, int32_t **nbr_cache, hipStream_t st,
+                       const int32_t *donor_nbr = nullptr, const int32_t *donor_size = nullptr) {
     if (K > 4096) SEI_FAIL("rulebook: filter volume too large");
     TiledRules t;
     t.n_dst = n_dst; t.n_src = n_src; t.K = K; t.tile_rows = tile_rows;
@@ -178,7 +190,11 @@ static int build_tiled(const int32_t *dst_coords, int64_t n_dst, int64_t n_src, 
     SEI_TRY(pool_alloc_t(&tile_subs, t.n_tiles + 1, st));
     SEI_TRY(pool_alloc_t(&totals, 4 + RULE_STRIPES, st));  // [2] = sub-chunk total (scan), [4..] = striped rule counts
     SEI_HIP(hipMemsetAsync(totals, 0, (4 + RULE_STRIPES) * sizeof(unsigned long long), st));
-    if (!*nbr_cache) {
+    NbrView vw{g.f0, g.f1, g.f2, g.f0, g.f1, g.f2};
+    if (!*nbr_cache && donor_nbr) {
+        // the offsets of this filter are a sub-set of the donor's table (same level, larger centred odd filter)
+        vw.F0 = donor_size[0]; vw.F1 = donor_size[1]; vw.F2 = donor_size[2];
+    } else if (!*nbr_cache) {
         int32_t *nbr;
         const int64_t tot = (int64_t)K * n_dst;
         SEI_TRY(pool_alloc_t(&nbr, tot, st));
@@ -193,8 +209,8 @@ static int build_tiled(const int32_t *dst_coords, int64_t n_dst, int64_t n_src, 
         SEI_LAUNCH_CHECK();
         *nbr_cache = nbr;
     }
-    const int32_t *nbr = *nbr_cache;
-    tile_rules_kernel<false><<<t.n_tiles, tile_rows, K * sizeof(int), st>>>(nbr, n_dst, K, tile_rows, t.n_tiles, tile_subs,
+    const int32_t *nbr = *nbr_cache ? *nbr_cache : donor_nbr;
+    tile_rules_kernel<false><<<t.n_tiles, tile_rows, K * sizeof(int), st>>>(nbr, vw, n_dst, K, tile_rows, t.n_tiles, tile_subs,
                                                                             t.tile_seg, t.seg_start, totals, nullptr, nullptr,
                                                                             nullptr);
     transpose_seg_kernel<<<dim3((t.n_tiles + 31) / 32, (K + 1 + 31) / 32), 256, 0, st>>>(t.tile_seg, t.seg_start, t.n_tiles, K + 1);
@@ -210,7 +226,7 @@ static int build_tiled(const int32_t *dst_coords, int64_t n_dst, int64_t n_src, 
     int64_t ns = t.n_sub > 0 ? t.n_sub : 1;
     SEI_TRY(pool_alloc_t(&t.sub_src, (ns + 1) * SUB_SLOTS, st));  // +1: the kernels' clamped index prefetch may touch the sub-chunk after the last
     SEI_TRY(pool_alloc_t(&t.sub_dst, (ns + 1) * SUB_SLOTS, st));
-    tile_rules_kernel<true><<<t.n_tiles, tile_rows, 0, st>>>(nbr, n_dst, K, tile_rows, t.n_tiles, nullptr, t.tile_seg, nullptr,
+    tile_rules_kernel<true><<<t.n_tiles, tile_rows, 0, st>>>(nbr, vw, n_dst, K, tile_rows, t.n_tiles, nullptr, t.tile_seg, nullptr,
                                                              nullptr, t.tile_sub_start, t.sub_src, t.sub_dst);
     SEI_LAUNCH_CHECK();
     pool_free(tile_subs); pool_free(totals);
@@ -230,7 +246,14 @@ int get_tiled(sei_rulebook *rb, bool transposed, int tile_rows, const TiledRules
                     rb->stride[2], rb->lin->spatial[0], rb->lin->spatial[1], rb->lin->spatial[2]};
         if (!transposed) {
             // dst = output sites probing the input-level hash
-            SEI_TRY(build_tiled(rb->lout->coords, rb->lout->n, rb->lin->n, rb->lin->ht, K, g, tile_rows, &t, &rb->nbr_fwd, st));
+            const int32_t *dn = nullptr, *ds = nullptr;
+            if (rb->submanifold && !rb->nbr_fwd && rb->donor) {
+                std::lock_guard<std::mutex> ld(rb->donor->mu);
+                dn = rb->donor->nbr_fwd;  // stays valid: rulebooks of one metadata are destroyed together
+                ds = rb->donor->size;
+            }
+            SEI_TRY(build_tiled(rb->lout->coords, rb->lout->n, rb->lin->n, rb->lin->ht, K, g, tile_rows, &t, &rb->nbr_fwd, st, dn,
+                                ds));
         } else {
             // dst = input sites probing the output-level hash
             g.mode = 2;

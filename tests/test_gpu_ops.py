@@ -76,6 +76,33 @@ def test_subm_rulebook_exact(filt):
     assert _rule_set(start, ri.cpu().numpy(), ro.cpu().numpy(), K) == _rule_set(ostart, ori, oro, K)
 
 
+@pytest.mark.parametrize("big,small", [([5, 5, 5], [3, 3, 3]), ([5, 5, 5], [1, 3, 3]), ([3, 5, 5], [3, 3, 1]), ([1, 5, 5], [1, 3, 3])])
+def test_subm_rulebook_cut_from_a_larger_filters_table(big, small):
+    """A submanifold rulebook whose level already holds one with a larger (centred, odd) filter -- the 5^3 stem next to
+    the 3^3 blocks of level 0 -- is cut from THAT rulebook's neighbour table instead of probing again: same rules as the
+    oracle, for two tile sizes."""
+    scn = _engine()
+    sp, B = [16, 12, 20], 2
+    coords, feats = blob_cloud(6, B, sp, 320, 1)
+    t, _ = _input(scn, coords, feats, B, sp)
+    rb_big = t.metadata.subm_rulebook(sp, big)
+    rb_big.stats(256)                                   # probes and keeps the table
+    rb = t.metadata.subm_rulebook(sp, small)
+    o = scn_cpu.input_layer(coords, torch.from_numpy(feats), B, sp)
+    ostart, ori, oro = scn_cpu.subm_rules(o.coords, sp, small)
+    K = small[0] * small[1] * small[2]
+    for tile_rows in (128, 64):
+        assert rb.stats(tile_rows)[0] == len(ori)
+    start, ri, ro = rb.export("cuda")
+    assert list(start) == [int(x) for x in ostart]
+    assert _rule_set(start, ri.cpu().numpy(), ro.cpu().numpy(), K) == _rule_set(ostart, ori, oro, K)
+    # and the donor's own rules are untouched
+    bstart, bri, bro = rb_big.export("cuda")
+    obs, obi, obo = scn_cpu.subm_rules(o.coords, sp, big)
+    Kb = big[0] * big[1] * big[2]
+    assert _rule_set(bstart, bri.cpu().numpy(), bro.cpu().numpy(), Kb) == _rule_set(obs, obi, obo, Kb)
+
+
 @pytest.mark.parametrize("sp,size,stride", [([16, 12, 20], [2, 2, 2], [2, 2, 2]), ([15, 13, 9], [2, 2, 2], [2, 2, 2]),
                                             ([3, 16, 12], [1, 2, 2], [1, 2, 2]), ([12, 12, 12], [3, 3, 3], [2, 2, 2])])
 def test_strided_rulebook_exact(sp, size, stride):
