@@ -110,10 +110,15 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--no-prof", action="store_true", help="skip HIP-event timing of the conv kernels")
+    ap.add_argument("--overlap-backward", action="store_true", help="dX and dW of a layer on two streams (SEI_BWD_STREAMS=1): "
+                    "361-363 vs 366 ms per step, but concurrent kernels' individual durations stop describing the kernels, so the "
+                    "roofline block of the JSON line is only meaningful without it")
     ap.add_argument("--prefetch", action="store_true", help="build step i+1's InputLayer hash + rulebooks on a side stream "
                     "during step i (Trainer.prefetch) instead of lazily inside the forward pass; measured 368.1 vs 370.1 ms "
                     "per step -- the conv kernels leave the rulebook kernels little room to overlap")
     args = ap.parse_args()
+    if args.overlap_backward:
+        os.environ["SEI_BWD_STREAMS"] = "1"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -289,6 +294,7 @@ def main():
                                       "fwd+bwd+Adam" if args.mode == "train" else "fwd", args.batch, args.voxels,
                                       grid[0], grid[1], grid[2], args.kind),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world,
+                       "backward": ("dX and dW of a layer on two streams" if args.overlap_backward else "dX and dW back to back"),
                        "rulebooks": ("step i+1's InputLayer hash + rulebooks on a side stream during step i (once per step, inside the timed region)"
                                      if (args.prefetch and args.mode == "train") else "built lazily in the forward pass")},
             "roofline": roof, "cpu_baseline": cpu,

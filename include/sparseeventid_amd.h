@@ -112,6 +112,13 @@ int sei_conv_backward_input_accumulate(sei_rulebook_t *rb, const float *dY, cons
 int sei_conv_backward_weight(sei_rulebook_t *rb, const float *X, const float *dY, float *dW, float *dbias,
                              int32_t nIn, int32_t nOut, sei_stream_t stream);
 
+/* dX and dW of one convolution in one call (either output may be NULL): the two are independent, the library runs dW on a
+ * side stream of its own next to dX on `stream` and joins before returning to `stream` -- same results as the two calls above
+ * (SCN's SubmanifoldConvolution_backward / Convolution_backward compute both in one call as well).  dX_init (optional):
+ * dX = dX_init + conv^T(dY), as sei_conv_backward_input_accumulate.  dbias (optional): column sums of dY. */
+int sei_conv_backward(sei_rulebook_t *rb, const float *X, const float *dY, const float *W, const float *dX_init,
+                      float *dX, float *dW, float *dbias, int32_t nIn, int32_t nOut, sei_stream_t stream);
+
 /* ---- BatchNormalization (+fused LeakyReLU, +fused residual AddTable)
  *      (scn.BatchNormalization / BatchNormLeakyReLU / BatchNormReLU + scn.AddTable + scn.LeakyReLU;
  *       sparse_building_blocks.py:39,80,96,122; SCN `BatchNormalization_updateOutput/_backward`) */

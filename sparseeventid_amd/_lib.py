@@ -39,6 +39,7 @@ _SIGNATURES = {
     "sei_conv_backward_input": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int32, ctypes.c_int32, vp]),
     "sei_conv_backward_input_accumulate": (ctypes.c_int, [vp, vp, vp, vp, vp, ctypes.c_int32, ctypes.c_int32, vp]),
     "sei_conv_backward_weight": (ctypes.c_int, [vp, vp, vp, vp, vp, ctypes.c_int32, ctypes.c_int32, vp]),
+    "sei_conv_backward": (ctypes.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_int32, ctypes.c_int32, vp]),
     "sei_bn_forward": (ctypes.c_int, [vp, ctypes.c_int64, ctypes.c_int32, vp, vp, vp, vp, ctypes.c_float, ctypes.c_float,
                                       ctypes.c_int32, ctypes.c_float, vp, vp, vp, vp, vp]),
     "sei_conv_bn_forward": (ctypes.c_int, [vp, vp, vp, vp, vp, ctypes.c_int32, ctypes.c_int32, vp, vp, vp, vp, ctypes.c_float,

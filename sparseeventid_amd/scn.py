@@ -231,13 +231,13 @@ class _Conv(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((rb.n_src, nIn), dtype=torch.float32, device=dout.device)
-            check(lib().sei_conv_backward_input(rb.h, _ptr(dout), _ptr(weight), _ptr(dx), nIn, nOut, _stream()))
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw = torch.empty_like(weight)
             if ctx.has_bias:
                 db = torch.empty((nOut,), dtype=torch.float32, device=dout.device)
-            check(lib().sei_conv_backward_weight(rb.h, _ptr(features), _ptr(dout), _ptr(dw), _ptr(db), nIn, nOut,
-                                                 _stream()))
+        if dx is not None or dw is not None:   # one call: the library overlaps dX and dW (dW on its own side stream)
+            check(lib().sei_conv_backward(rb.h, _ptr(features), _ptr(dout), _ptr(weight), None, _ptr(dx), _ptr(dw), _ptr(db),
+                                          nIn, nOut, _stream()))
         return dx, dw, db, None
 
 
@@ -323,10 +323,9 @@ class _ResidualBlock(torch.autograd.Function):
         db2 = vec() if ctx.has_b2 else None
         check(L.sei_bn_backward_colsum(_ptr(y2), _ptr(out), _ptr(dout), n, C, _ptr(g2), None, _ptr(m2), _ptr(s2), ctx.leak2,
                                        tr2, _ptr(dy2), _ptr(dres), _ptr(dg2), _ptr(dbe2), _ptr(db2), st))
-        dw2 = torch.empty_like(w2)
-        check(L.sei_conv_backward_weight(rb.h, _ptr(a1), _ptr(dy2), _ptr(dw2), None, C, C, st))
-        da1 = torch.empty_like(x)
-        check(L.sei_conv_backward_input(rb.h, _ptr(dy2), _ptr(w2), _ptr(da1), C, C, st))
+        dw2, da1 = torch.empty_like(w2), torch.empty_like(x)
+        # dW and dX of a layer in one call: the library overlaps them (dW on its own side stream)
+        check(L.sei_conv_backward(rb.h, _ptr(a1), _ptr(dy2), _ptr(w2), None, _ptr(da1), _ptr(dw2), None, C, C, st))
         del dy2
         dy1, dg1, dbe1 = torch.empty_like(x), vec(), vec()
         db1 = vec() if ctx.has_b1 else None
@@ -335,12 +334,10 @@ class _ResidualBlock(torch.autograd.Function):
                                        tr1, _ptr(dy1), None, _ptr(dg1), _ptr(dbe1), _ptr(db1), st))
         del da1
         dw1 = torch.empty_like(w1)
-        check(L.sei_conv_backward_weight(rb.h, _ptr(x), _ptr(dy1), _ptr(dw1), None, C, C, st))
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
-            # dX = dres + conv1^T(dy1): the skip gradient seeds the kernel's accumulators
-            check(L.sei_conv_backward_input_accumulate(rb.h, _ptr(dy1), _ptr(w1), _ptr(dres), _ptr(dx), C, C, st))
+        # dX = dres + conv1^T(dy1): the skip gradient seeds the kernel's accumulators; dW beside it
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        check(L.sei_conv_backward(rb.h, _ptr(x), _ptr(dy1), _ptr(w1), _ptr(dres) if dx is not None else None, _ptr(dx),
+                                  _ptr(dw1), None, C, C, st))
         return (dx, None, dw1, db1, dg1, dbe1, None, None, dw2, db2, dg2, dbe2, None, None, None, None, None, None)
 
 
@@ -387,13 +384,10 @@ class _ConvBN(torch.autograd.Function):
         check(L.sei_bn_backward_colsum(_ptr(y), _ptr(a) if ctx.has_res else None, _ptr(da), n, nOut, _ptr(gamma), _ptr(beta),
                                        _ptr(mean), _ptr(invstd), ctx.leak, 1 if ctx.training else 0, _ptr(dy), _ptr(dres),
                                        _ptr(dg), _ptr(dbe), _ptr(db), st))
-        dx = dw = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.empty((rb.n_src, nIn), dtype=torch.float32, device=dev)
-            check(L.sei_conv_backward_input(rb.h, _ptr(dy), _ptr(w), _ptr(dx), nIn, nOut, st))
-        if ctx.needs_input_grad[2]:
-            dw = torch.empty_like(w)
-            check(L.sei_conv_backward_weight(rb.h, _ptr(x), _ptr(dy), _ptr(dw), None, nIn, nOut, st))
+        dx = torch.empty((rb.n_src, nIn), dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(w) if ctx.needs_input_grad[2] else None
+        if dx is not None or dw is not None:   # one call: the library overlaps dX and dW (dW on its own side stream)
+            check(L.sei_conv_backward(rb.h, _ptr(x), _ptr(dy), _ptr(w), None, _ptr(dx), _ptr(dw), None, nIn, nOut, st))
         return dx, None, dw, db, dg, dbe, None, None, None, None, None, None, dres
 
 

@@ -97,3 +97,24 @@ def test_training_with_prefetch_is_bit_identical_to_lazy_training():
     assert torch.equal(lazy.arena.flat, pre.arena.flat)
     for (k, a), (_, b) in zip(lazy.encoder.named_buffers(), pre.encoder.named_buffers()):
         assert torch.equal(a, b), k
+
+
+def test_two_stream_backward_is_bit_identical(monkeypatch):
+    """SEI_BWD_STREAMS=1: dW of every layer on the library's side stream next to dX (sei_conv_backward) -- same kernels,
+    same results; also together with the prefetch."""
+    base, over = _trainer(), _trainer()
+    batches = _batches(base)
+    order = [0, 1, 2, 1]
+    torch.manual_seed(77)
+    for i in order:
+        base.train_step(*batches[i])
+    monkeypatch.setenv("SEI_BWD_STREAMS", "1")
+    torch.manual_seed(77)
+    staged = over.prefetch(batches[order[0]][0])
+    for j, i in enumerate(order):
+        over.train_step(staged, batches[i][1])
+        if j + 1 < len(order):
+            staged = over.prefetch(batches[order[j + 1]][0])
+    torch.cuda.synchronize()
+    assert torch.equal(base.arena.flat, over.arena.flat)
+
