@@ -47,7 +47,7 @@ def generate_batch(rank, batch_index, batch, grid, nvox, kind, workers):
     return arr, labels
 
 
-def cpu_baseline(arr, labels, image_size, n_events, fwd_only, threads=16, warmup=1, passes=3):
+def cpu_baseline(arr, labels, image_size, n_events, fwd_only, threads=16, warmup=2, passes=5):
     """Time the CPU restatement of the SCN-CPU algorithm (the SCN binary is unavailable) on the first `n_events`
     events of the same batch: C++/OpenMP inner loops (oracle/scn_omp.cpp: host hash + rule lists probed by all cores,
     per offset gather -> sgemm (OpenBLAS) -> scatter-add, two-pass BatchNorm, LeakyReLU) under the reference topology
@@ -109,16 +109,17 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=16, help="torch threads of the CPU-baseline leg")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--force-pg", action="store_true", help="initialise the process group (default backend nccl = RCCL) even at "
+                    "--gpus 1: the gradient all-reduce, parameter / buffer broadcasts and the cross-rank checks then really run "
+                    "through the backend at world size 1")
     ap.add_argument("--no-prof", action="store_true", help="skip HIP-event timing of the conv kernels")
-    ap.add_argument("--overlap-backward", action="store_true", help="dX and dW of a layer on two streams (SEI_BWD_STREAMS=1): "
+    ap.add_argument("--overlap-backward", action="store_true", help="dX and dW of a layer on two streams (sei_set_backward_streams): "
                     "361-363 vs 366 ms per step, but concurrent kernels' individual durations stop describing the kernels, so the "
                     "roofline block of the JSON line is only meaningful without it")
     ap.add_argument("--prefetch", action="store_true", help="build step i+1's InputLayer hash + rulebooks on a side stream "
                     "during step i (Trainer.prefetch) instead of lazily inside the forward pass; measured 368.1 vs 370.1 ms "
                     "per step -- the conv kernels leave the rulebook kernels little room to overlap")
     args = ap.parse_args()
-    if args.overlap_backward:
-        os.environ["SEI_BWD_STREAMS"] = "1"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -128,7 +129,8 @@ def main():
 
     # synthetic input is generated BEFORE the GPU is touched (fork pool)
     ncpu = os.cpu_count() or 8
-    workers = int(os.environ.get("SEI_GEN_WORKERS", "0")) or max(1, min(16, ncpu // max(world, 1)))
+    # half of this rank's share of the host's cores: 8 ranks on one host must not oversubscribe it while they all generate
+    workers = int(os.environ.get("SEI_GEN_WORKERS", "0")) or max(1, min(16, ncpu // (2 * max(world, 1))))
     # (under `rocprofv3 --pmc` the GPU is initialised before python starts: set SEI_GEN_WORKERS=1, no fork)
     grid = tuple(args.grid)
     if args.model == "sbnd":
@@ -150,7 +152,11 @@ def main():
     torch.cuda.set_device(local)
     if world > 1:
         os.environ["LOCAL_RANK"] = str(local)
-    init_from_env(args.backend if world > 1 else None)
+    grouped = world > 1 or args.force_pg
+    if args.force_pg and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+    init_from_env(args.backend if grouped else None, force=args.force_pg)
     image_size = [1] + list(grid)
     tr = Trainer(image_size=image_size, device="cuda", seed=0, model="sbnd" if args.model == "sbnd" else "resnet")
     tr.arena.broadcast_parameters()
@@ -173,13 +179,15 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
 
+    lib = _lib.lib()
+    if args.overlap_backward:
+        lib.sei_set_backward_streams(1)
     for _ in range(args.warmup):
         step()
-    lib = _lib.lib()
     fence()
     if not args.no_prof:
         lib.sei_prof_reset()
@@ -192,7 +200,7 @@ def main():
     lib.sei_prof_enable(0)
     ms = dt / args.steps * 1e3
     sync = None
-    if world > 1:
+    if grouped:
         t = torch.tensor([ms], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         ms = float(t.item())
@@ -210,7 +218,7 @@ def main():
         if len({float(x.item()) for x in sigs}) != world:
             raise SystemExit("ranks were given identical batches")
         sync = {"parameters_bit_identical_across_ranks": args.mode == "train", "distinct_batches": True,
-                "backend": args.backend, "one_device": bool(args.one_device)}
+                "backend": dist.get_backend(), "world_size": world, "one_device": bool(args.one_device)}
 
     staging = None
     if world == 1 and args.mode == "train" and args.model == "dune3d":
@@ -256,15 +264,23 @@ def main():
             if tot_ms > 0:
                 ach = tot_fl / (tot_ms * 1e-3) / 1e12
                 # HBM traffic cannot be read live: it comes from the committed PMC passes of this same command
-                traffic = None
-                tpath = os.path.join(ROOT, "profiles", "r02_conv_fwd_hbm_traffic.json")
+                # (tools/traffic.sh); the file's git blob hash is emitted beside it so that a stale file shows
+                traffic = traffic_src = None
+                tname = "r03_conv_fwd_hbm_traffic.json"
+                tpath = os.path.join(ROOT, "profiles", tname)
                 if (os.path.exists(tpath) and args.model == "dune3d" and args.mode == "train" and args.batch == 64
-                        and args.voxels == 50000 and args.kind == "tracks"):
-                    traffic = json.load(open(tpath))["traffic_bytes_per_launch"]
+                        and args.voxels == 50000 and args.kind == "tracks" and grid == (900, 900, 900)):
+                    import hashlib
+                    raw = open(tpath, "rb").read()
+                    tj = json.loads(raw)
+                    traffic = tj["traffic_bytes_per_launch"]
+                    traffic_src = {"file": "profiles/" + tname, "git_blob": hashlib.sha1(b"blob %d\0" % len(raw) + raw).hexdigest(),
+                                   "measured_at_commit": tj.get("commit")}
                 roof = {"bound": "mfma", "kernel": "conv_tile_mfma_kernel + conv_wave_mfma_kernel (all forward + dX launches)",
                         "achieved": ach, "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3, "traffic": traffic,
+                        "traffic_source": traffic_src,
                         "traffic_note": "HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
-                                        "(profiles/r02_conv_fwd_hbm_traffic.json); algorithmic bytes per launch %.3g"
+                                        "(tools/traffic.sh); algorithmic bytes per launch %.3g"
                                         % ((kinds["conv_fwd"]["gbyte"] + kinds["conv_bwd_input"]["gbyte"]) * 1e9 / max(tot_n, 1)),
                         "launches_per_step": tot_n / args.steps, "avg_launch_ms": tot_ms / max(tot_n, 1),
                         "per_kind_per_step": {k: {kk: vv / args.steps for kk, vv in v.items()} for k, v in kinds.items()}}
@@ -304,7 +320,7 @@ def main():
         if staging is not None:
             out["staging_inclusive"] = staging
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 

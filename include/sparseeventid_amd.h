@@ -42,6 +42,10 @@ int sei_abi_version(void);
 
 /* ---- metadata (replaces scn.Metadata / SCN `Metadata<3>`) ------------------------------- */
 int sei_metadata_create(sei_metadata_t **out);
+/* Streams: a metadata may be built on one stream (sei_input_build, sei_metadata_prebuild_like) and its rulebooks read by
+ * kernels the caller queues on other streams; the caller orders the BUILD before those kernels (event / wait_stream).
+ * Destroying it needs no ordering: its device blocks are released behind a fence of one event per stream the library has
+ * been handed, recorded at the time of this call, and are reused only when all of them have completed. */
 void sei_metadata_destroy(sei_metadata_t *m);
 
 /* scn.InputLayer(dimension=3, spatial_size, mode) coordinate pass (resnet.py:40-43,143;
@@ -112,12 +116,20 @@ int sei_conv_backward_input_accumulate(sei_rulebook_t *rb, const float *dY, cons
 int sei_conv_backward_weight(sei_rulebook_t *rb, const float *X, const float *dY, float *dW, float *dbias,
                              int32_t nIn, int32_t nOut, sei_stream_t stream);
 
-/* dX and dW of one convolution in one call (either output may be NULL): the two are independent, the library runs dW on a
- * side stream of its own next to dX on `stream` and joins before returning to `stream` -- same results as the two calls above
- * (SCN's SubmanifoldConvolution_backward / Convolution_backward compute both in one call as well).  dX_init (optional):
+/* dX and dW of one convolution in one call (either output may be NULL) -- same results as the two calls above (SCN's
+ * SubmanifoldConvolution_backward / Convolution_backward compute both in one call as well).  Back to back on `stream` by
+ * default; after sei_set_backward_streams(1) the library runs dW on a side stream of its own (one per device and caller
+ * stream) next to dX on `stream` and joins before returning to `stream`.  dX_init (optional):
  * dX = dX_init + conv^T(dY), as sei_conv_backward_input_accumulate.  dbias (optional): column sums of dY. */
 int sei_conv_backward(sei_rulebook_t *rb, const float *X, const float *dY, const float *W, const float *dX_init,
                       float *dX, float *dW, float *dbias, int32_t nIn, int32_t nOut, sei_stream_t stream);
+
+/* process-wide switch for sei_conv_backward (0 = back to back, the default; 1 = dW on the library's side stream) */
+int sei_set_backward_streams(int32_t on);
+/* Test / sweep hook: pins the forward / dX kernel family for every later convolution of the process
+ * (0 = the plan picks (default), 1 = workgroup-tile kernel, 2 = wave-private kernel, 3 = row-band kernel).  The
+ * families produce bit-identical results (same per-row summation order); tests/test_gpu_kernels_agree.py asserts it. */
+int sei_debug_force_conv_kernel(int32_t kind);
 
 /* ---- BatchNormalization (+fused LeakyReLU, +fused residual AddTable)
  *      (scn.BatchNormalization / BatchNormLeakyReLU / BatchNormReLU + scn.AddTable + scn.LeakyReLU;
@@ -172,7 +184,7 @@ int sei_sparse_to_dense_backward(sei_metadata_t *m, const int32_t spatial[3], co
 
 /* ---- fused sparse head (opt-in): AvgPool3d_full(tanh(SparseToDense(x))) without the dense
  *      tensor (resnet.py:156-159 + classification_head.py:19-21): pooled[B,C] = sum_active tanh(x) / volume.
- *      Uses float atomics: equal to the dense path within rounding, summation order not fixed. */
+ *      Fixed-order two-stage reduction (no float atomics): bit-identical reruns. */
 int sei_pool_tanh_forward(sei_metadata_t *m, const int32_t spatial[3], const float *feats, int32_t C, float *pooled,
                           sei_stream_t stream);
 int sei_pool_tanh_backward(sei_metadata_t *m, const int32_t spatial[3], const float *feats, const float *dpooled,

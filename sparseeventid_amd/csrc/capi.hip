@@ -1,6 +1,7 @@
 // C ABI glue (include/sparseeventid_amd.h): error state, device pool, profiling, handle management.
 #include "common.h"
 
+#include <atomic>
 #include <map>
 
 #include <string.h>
@@ -19,12 +20,57 @@ struct PoolBlock {
     hipStream_t stream;
 };
 typedef std::pair<int, hipStream_t> PoolKey;
+// Blocks that work on SEVERAL streams may still be reading when they are freed (hash tables, rule lists, neighbour tables
+// of a metadata: built on one stream, read by forward / backward kernels on others).  They are released behind a fence:
+// one event per stream the library has been handed on that device, recorded at the time of the free; the blocks return to
+// their free list only once every one of those events has completed, i.e. when everything queued before the free -- on
+// any stream -- is done.
+struct Fence {
+    std::vector<hipEvent_t> events;
+    int blocks = 0;  // quarantined blocks still waiting on this fence
+};
+struct Quarantined {
+    void *p;
+    PoolBlock b;
+    Fence *fence;
+};
 struct Pool {
     std::mutex mu;
     std::map<PoolKey, std::multimap<size_t, void *>> free_blocks;
     std::map<void *, PoolBlock> live;
+    std::vector<Quarantined> quarantine;
+    std::vector<PoolKey> streams;        // every (device, stream) the library has launched work on
+    std::vector<hipEvent_t> spare_events;
     size_t held = 0, in_use = 0;
 } g_pool;
+
+bool fence_done_locked(Fence *f) {
+    while (!f->events.empty()) {
+        hipError_t e = hipEventQuery(f->events.back());
+        if (e == hipErrorNotReady) {
+            (void)hipGetLastError();
+            return false;
+        }
+        g_pool.spare_events.push_back(f->events.back());
+        f->events.pop_back();
+    }
+    return true;
+}
+
+// quarantined blocks whose fence has completed go back to their free lists
+void reap_quarantine_locked() {
+    size_t keep = 0;
+    for (size_t i = 0; i < g_pool.quarantine.size(); i++) {
+        Quarantined q = g_pool.quarantine[i];
+        if (fence_done_locked(q.fence)) {
+            g_pool.free_blocks[PoolKey(q.b.device, q.b.stream)].emplace(q.b.size, q.p);
+            if (--q.fence->blocks == 0) delete q.fence;
+        } else {
+            g_pool.quarantine[keep++] = q;
+        }
+    }
+    g_pool.quarantine.resize(keep);
+}
 
 size_t round_size(size_t b) {
     if (b < 256) return 256;
@@ -47,11 +93,26 @@ void release_cached_locked() {
 }
 }  // namespace
 
+void note_stream(hipStream_t st) {
+    static thread_local PoolKey last(-1, nullptr);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const PoolKey key(dev, st);
+    if (key == last) return;
+    last = key;
+    std::lock_guard<std::mutex> lk(g_pool.mu);
+    for (const PoolKey &k : g_pool.streams)
+        if (k == key) return;
+    g_pool.streams.push_back(key);
+}
+
 void *pool_alloc(size_t bytes, hipStream_t st) {
     size_t sz = round_size(bytes);
+    note_stream(st);
     int dev = 0;
     (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lk(g_pool.mu);
+    if (!g_pool.quarantine.empty()) reap_quarantine_locked();
     auto &fl = g_pool.free_blocks[PoolKey(dev, st)];
     auto it = fl.lower_bound(sz);
     if (it != fl.end() && it->first <= sz + sz / 4 + (1u << 20)) {
@@ -66,6 +127,9 @@ void *pool_alloc(size_t bytes, hipStream_t st) {
     hipError_t e = hipMalloc(&p, sz);
     if (e != hipSuccess) {
         // release cached blocks (all streams: the allocator call itself synchronises) and retry once
+        (void)hipGetLastError();
+        (void)hipDeviceSynchronize();
+        reap_quarantine_locked();
         release_cached_locked();
         (void)hipGetLastError();
         e = hipMalloc(&p, sz);
@@ -89,6 +153,52 @@ void pool_free(void *p) {
     g_pool.free_blocks[PoolKey(b.device, b.stream)].emplace(b.size, p);
     g_pool.in_use -= b.size;
     g_pool.live.erase(it);
+}
+
+PoolFence pool_fence_begin() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(g_pool.mu);
+    Fence *f = new Fence();
+    for (const PoolKey &k : g_pool.streams) {
+        if (k.first != dev) continue;
+        hipEvent_t ev = nullptr;
+        if (!g_pool.spare_events.empty()) {
+            ev = g_pool.spare_events.back();
+            g_pool.spare_events.pop_back();
+        } else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            continue;
+        }
+        if (hipEventRecord(ev, k.second) != hipSuccess) {   // a stream the caller has destroyed meanwhile: nothing left on it
+            (void)hipGetLastError();
+            g_pool.spare_events.push_back(ev);
+            continue;
+        }
+        f->events.push_back(ev);
+    }
+    return f;
+}
+
+void pool_free_fenced(void *p, PoolFence fence) {
+    if (!p) return;
+    Fence *f = (Fence *)fence;
+    std::lock_guard<std::mutex> lk(g_pool.mu);
+    auto it = g_pool.live.find(p);
+    if (it == g_pool.live.end()) return;
+    g_pool.quarantine.push_back(Quarantined{p, it->second, f});
+    f->blocks++;
+    g_pool.in_use -= it->second.size;
+    g_pool.live.erase(it);
+}
+
+void pool_fence_end(PoolFence fence) {
+    Fence *f = (Fence *)fence;
+    std::lock_guard<std::mutex> lk(g_pool.mu);
+    if (f->blocks == 0) {
+        for (hipEvent_t ev : f->events) g_pool.spare_events.push_back(ev);
+        delete f;
+    }
 }
 
 int ensure_max_lds(const void *kernel, int bytes) {
@@ -166,13 +276,33 @@ ProfScope::~ProfScope() {
 
 }  // namespace sei
 
+static std::atomic<int> g_force_kernel{0};
+namespace sei {
+int forced_conv_kernel() {
+#ifdef SEI_EXPERIMENTS  // the sweep tools of a kernel-experiment build may also pin the family through the environment
+    if (const char *e = getenv("SEI_CONV_KERNEL")) {
+        if (!strcmp(e, "tile")) return CONV_KERNEL_TILE;
+        if (!strcmp(e, "wave")) return CONV_KERNEL_WAVE;
+        if (!strcmp(e, "band")) return CONV_KERNEL_BAND;
+    }
+#endif
+    return g_force_kernel.load(std::memory_order_relaxed);
+}
+}  // namespace sei
+
 using namespace sei;
 
-static void free_level(Level *l) {
-    pool_free(l->coords);
-    pool_free(l->ht.keys);
-    pool_free(l->ht.vals);
+static void free_level(Level *l, PoolFence f) {
+    pool_free_fenced(l->coords, f);
+    pool_free_fenced(l->ht.keys, f);
+    pool_free_fenced(l->ht.vals, f);
     delete l;
+}
+
+static void free_tiled_fenced(TiledRules &t, PoolFence f) {
+    pool_free_fenced(t.tile_sub_start, f); pool_free_fenced(t.tile_seg, f); pool_free_fenced(t.seg_start, f);
+    pool_free_fenced(t.sub_src, f); pool_free_fenced(t.sub_dst, f);
+    t = TiledRules();
 }
 
 extern "C" {
@@ -193,20 +323,26 @@ int sei_metadata_create(sei_metadata_t **out) {
 
 void sei_metadata_destroy(sei_metadata_t *m) {
     if (!m) return;
+    // kernels on other streams than the one that built them may still be reading these blocks (forward / backward on the
+    // caller's streams, dW on the library's side stream): they are reusable once everything queued so far is done
+    PoolFence f = pool_fence_begin();
     for (auto *rb : m->rulebooks) {
         for (int v = 0; v < SEI_NVARIANT; v++) {
-            free_tiled(rb->fwd[v]);
-            free_tiled(rb->bwd[v]);
+            free_tiled_fenced(rb->fwd[v], f);
+            free_tiled_fenced(rb->bwd[v], f);
         }
-        pool_free(rb->nbr_fwd);
-        pool_free(rb->nbr_bwd);
+        pool_free_fenced(rb->nbr_fwd, f);
+        pool_free_fenced(rb->nbr_bwd, f);
         delete rb;
     }
-    for (auto *l : m->levels) free_level(l);
-    pool_free(m->input_row);
-    pool_free(m->row_first);
-    pool_free(m->row_last);
-    pool_free(m->row_count);
+    for (auto *l : m->levels) free_level(l, f);
+    pool_free_fenced(m->input_row, f);
+    pool_free_fenced(m->row_first, f);
+    pool_free_fenced(m->row_last, f);
+    pool_free_fenced(m->row_count, f);
+    pool_free_fenced(m->dup_order, f);
+    pool_free_fenced(m->dup_start, f);
+    pool_fence_end(f);
     delete m;
 }
 
@@ -229,10 +365,12 @@ int sei_larcv_to_scn(const float *larcv_dev, int32_t B, int32_t P, int32_t M, in
 
 int sei_input_features_fwd(sei_metadata_t *m, const float *in, int32_t C, float *out, sei_stream_t stream) {
     if (!m) SEI_FAIL("null metadata");
+    note_stream((hipStream_t)stream);
     return input_features_fwd(m, in, C, out, (hipStream_t)stream);
 }
 int sei_input_features_bwd(sei_metadata_t *m, const float *dout, int32_t C, float *din, sei_stream_t stream) {
     if (!m) SEI_FAIL("null metadata");
+    note_stream((hipStream_t)stream);
     return input_features_bwd(m, dout, C, din, (hipStream_t)stream);
 }
 
@@ -412,6 +550,7 @@ struct AlignedArg {
 static int conv_forward_impl(sei_rulebook_t *rb, const float *X, const float *W, const float *bias, float *Y, int32_t nIn,
                              int32_t nOut, hipStream_t st, double **stats_out, int64_t *parts_out) {
     if (!rb) SEI_FAIL("null rulebook");
+    note_stream(st);
     const TiledRules *t;
     const int64_t n_dst = rb->lout ? rb->lout->n : 0;
     const ConvPlan p = plan_conv(nIn, nOut, rulebook_K(rb), n_dst);
@@ -474,6 +613,7 @@ static int conv_backward_input_impl(sei_rulebook_t *rb, const float *dY, const f
                                     int32_t nIn, int32_t nOut, sei_stream_t stream) {
     if (!rb) SEI_FAIL("null rulebook");
     hipStream_t st = (hipStream_t)stream;
+    note_stream(st);
     const TiledRules *t;
     // roles swap: contraction over nOut, result has nIn columns
     const int64_t n_dst = rb->lin ? rb->lin->n : 0;
@@ -524,20 +664,48 @@ int sei_conv_backward_weight(sei_rulebook_t *rb, const float *X, const float *dY
     return 0;
 }
 
-// dX and dW of one layer are independent.  With SEI_BWD_STREAMS=1 the combined entry point runs dW on a library-owned side
-// stream next to dX on the caller's stream (fork after everything already queued on `stream`, join before returning to it),
-// so that the tail of one kernel -- CUs idle while the last workgroups finish -- is filled by the other: 361-363 vs 366 ms
-// per step.  Both rule variants are built on the caller's stream BEFORE the fork.  Default: back to back -- concurrent
-// kernels share the GPU, so their individual durations (HIP events, rocprof) stop describing the kernels, and the roofline
-// accounting of bench.py is built on those durations.
+// dX and dW of one layer are independent.  With sei_set_backward_streams(1) the combined entry point runs dW on a
+// library-owned side stream (one per device and caller stream) next to dX on the caller's stream (fork after everything
+// already queued on `stream`, join before returning to it), so that the tail of one kernel -- CUs idle while the last
+// workgroups finish -- is filled by the other: 361-363 vs 366 ms per step.  Both rule variants are built on the caller's
+// stream BEFORE the fork.  Default: back to back -- concurrent kernels share the GPU, so their individual durations (HIP
+// events, rocprof) stop describing the kernels, and the roofline accounting of bench.py is built on those durations.
 namespace {
 struct SideStream {
     hipStream_t s = nullptr;
     hipEvent_t e_in = nullptr, e_done = nullptr;
 };
 std::mutex g_side_mu;
-std::map<int, SideStream> g_side;
+std::map<std::pair<int, hipStream_t>, SideStream> g_side;
+std::atomic<int> g_bwd_streams{0};
+
+// the side stream paired with (device, caller stream); the mutex covers the lazy creation only
+int side_stream_for(hipStream_t st, SideStream *out) {
+    int dev = 0;
+    SEI_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    SideStream &ss = g_side[std::make_pair(dev, st)];
+    if (!ss.s) {
+        SEI_HIP(hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking));
+        SEI_HIP(hipEventCreateWithFlags(&ss.e_in, hipEventDisableTiming));
+        SEI_HIP(hipEventCreateWithFlags(&ss.e_done, hipEventDisableTiming));
+    }
+    *out = ss;
+    return 0;
+}
 }  // namespace
+
+
+int sei_set_backward_streams(int32_t on) {
+    g_bwd_streams.store(on ? 1 : 0);
+    return 0;
+}
+
+int sei_debug_force_conv_kernel(int32_t kind) {
+    if (kind < CONV_KERNEL_AUTO || kind > CONV_KERNEL_BAND) SEI_FAIL("sei_debug_force_conv_kernel: kind must be 0..3");
+    g_force_kernel.store(kind);
+    return 0;
+}
 
 int sei_conv_backward(sei_rulebook_t *rb, const float *X, const float *dY, const float *W, const float *dX_init, float *dX,
                       float *dW, float *dbias, int32_t nIn, int32_t nOut, sei_stream_t stream) {
@@ -547,20 +715,12 @@ int sei_conv_backward(sei_rulebook_t *rb, const float *X, const float *dY, const
     if (!dX && !dW) return 0;
     if (!dW) return conv_backward_input_impl(rb, dY, W, dX_init, dX, nIn, nOut, stream);
     if (!dX) return sei_conv_backward_weight(rb, X, dY, dW, nullptr, nIn, nOut, stream);
-    const char *e = getenv("SEI_BWD_STREAMS");
-    int dev = 0;
-    SEI_HIP(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> lk(g_side_mu);
-    SideStream &ss = g_side[dev];
-    if (!ss.s) {
-        SEI_HIP(hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking));
-        SEI_HIP(hipEventCreateWithFlags(&ss.e_in, hipEventDisableTiming));
-        SEI_HIP(hipEventCreateWithFlags(&ss.e_done, hipEventDisableTiming));
-    }
-    if (!e || atoi(e) == 0 || st == ss.s) {
+    if (!g_bwd_streams.load(std::memory_order_relaxed)) {   // default: back to back, no stream, no lock
         SEI_TRY(sei_conv_backward_weight(rb, X, dY, dW, nullptr, nIn, nOut, stream));
         return conv_backward_input_impl(rb, dY, W, dX_init, dX, nIn, nOut, stream);
     }
+    SideStream ss;
+    SEI_TRY(side_stream_for(st, &ss));
     // rule variants of both kernels on the caller's stream (cached after the first call of a level)
     const TiledRules *tw, *tx;
     SEI_TRY(get_tiled(rb, false, 256, &tw, st));
@@ -621,6 +781,7 @@ int sei_add_leaky_forward(const float *a, const float *b, float *y, int64_t coun
 
 int sei_sparse_to_dense_forward(sei_metadata_t *m, const int32_t spatial[3], const float *feats, int32_t C, float *dense,
                                 sei_stream_t stream) {
+    note_stream((hipStream_t)stream);
     std::lock_guard<std::mutex> lk(m->mu);
     Level *l = find_level(m, spatial);
     if (!l) SEI_FAIL("SparseToDense: no level with this spatial size in the metadata");
@@ -628,6 +789,7 @@ int sei_sparse_to_dense_forward(sei_metadata_t *m, const int32_t spatial[3], con
 }
 int sei_sparse_to_dense_backward(sei_metadata_t *m, const int32_t spatial[3], const float *ddense, int32_t C,
                                  float *dfeats, sei_stream_t stream) {
+    note_stream((hipStream_t)stream);
     std::lock_guard<std::mutex> lk(m->mu);
     Level *l = find_level(m, spatial);
     if (!l) SEI_FAIL("SparseToDense: no level with this spatial size in the metadata");
@@ -636,6 +798,7 @@ int sei_sparse_to_dense_backward(sei_metadata_t *m, const int32_t spatial[3], co
 
 int sei_pool_tanh_forward(sei_metadata_t *m, const int32_t spatial[3], const float *feats, int32_t C, float *pooled,
                           sei_stream_t stream) {
+    note_stream((hipStream_t)stream);
     std::lock_guard<std::mutex> lk(m->mu);
     Level *l = find_level(m, spatial);
     if (!l) SEI_FAIL("pool_tanh: no level with this spatial size in the metadata");
@@ -643,6 +806,7 @@ int sei_pool_tanh_forward(sei_metadata_t *m, const int32_t spatial[3], const flo
 }
 int sei_pool_tanh_backward(sei_metadata_t *m, const int32_t spatial[3], const float *feats, const float *dpooled,
                            int32_t C, float *dfeats, sei_stream_t stream) {
+    note_stream((hipStream_t)stream);
     std::lock_guard<std::mutex> lk(m->mu);
     Level *l = find_level(m, spatial);
     if (!l) SEI_FAIL("pool_tanh: no level with this spatial size in the metadata");
@@ -676,6 +840,7 @@ int sei_pool_stats(int64_t *bytes_held, int64_t *bytes_in_use) {
 }
 int sei_pool_trim(void) {
     std::lock_guard<std::mutex> lk(g_pool.mu);
+    reap_quarantine_locked();
     release_cached_locked();
     return 0;
 }

@@ -43,6 +43,13 @@ void set_error(const std::string &msg);
 // memory of its own instead of aliasing it.
 void *pool_alloc(size_t bytes, hipStream_t st);
 void pool_free(void *p);
+// Blocks that kernels on OTHER streams may still be reading (everything a metadata owns): freed behind a fence = one
+// event per stream the library has been handed, recorded now; reusable once all of them have completed.
+typedef void *PoolFence;
+PoolFence pool_fence_begin();
+void pool_free_fenced(void *p, PoolFence fence);
+void pool_fence_end(PoolFence fence);
+void note_stream(hipStream_t st);  // remembers a stream the library launches work on (entry points that take a stream)
 template <typename T>
 inline int pool_alloc_t(T **out, size_t count, hipStream_t st) {
     *out = (T *)pool_alloc(count * sizeof(T) + 16, st);
@@ -180,6 +187,8 @@ struct sei_metadata {
     int32_t *row_first = nullptr; // [n_rows] first input index of row
     int32_t *row_last = nullptr;  // [n_rows]
     int32_t *row_count = nullptr; // [n_rows]
+    int32_t *dup_order = nullptr; // [n_input] point indices sorted by row, input order inside a row (only with duplicate points)
+    int32_t *dup_start = nullptr; // [n_rows+1] first entry of each row in dup_order
     std::vector<sei::Level *> levels;
     std::vector<sei_rulebook *> rulebooks;
 };
@@ -220,6 +229,10 @@ struct ConvPlan {
     size_t lds_bytes = 0;
 };
 ConvPlan plan_conv(int nIn, int nOut, int K, int64_t n_dst);
+// sei_debug_force_conv_kernel(): pins the forward / dX kernel family for every later call of the process
+// (bit-identity tests between the kernels, sweeps); AUTO = the plan picks
+enum { CONV_KERNEL_AUTO = 0, CONV_KERNEL_TILE = 1, CONV_KERNEL_WAVE = 2, CONV_KERNEL_BAND = 3 };
+int forced_conv_kernel();
 bool plan_wave(int nIn, int nOut, int K, int64_t n_dst, ConvPlan *p);
 // stats (optional, MFMA kernels only): per-(tile, part) column sums of the OUTPUT rows, [n_parts][2][nOut] doubles
 // (sum, sum of squares) accumulated in the kernel epilogue from the LDS tile -- BatchNorm statistics without a second

@@ -428,17 +428,22 @@ int conv_backward_weight(const TiledRules &t, const float *X, const float *dY, f
         }
         if (nt == 6 && ct % 2 == 0) mt = 2;  // 96 planes: 2x6 tiles (one dwordx2 + dwordx4/x2 per step) measured 4 % faster than 3x6
         if (!mt) mfma_ok = false;
-        if (const char *e = getenv("SEI_DW_MT")) {  // kernel experiments
+#ifdef SEI_EXPERIMENTS  // tools/dw_micro.py
+        if (const char *e = getenv("SEI_DW_MT")) {
             int em = atoi(e);
             if (em >= 1 && em <= 4 && ct % em == 0 && em * nt <= 48) mt = em;
         }
+#endif
     }
     bool small = !mfma_ok && nIn <= 4 && (nOut == 16 || nOut == 32 || nOut == 64);
     // splits: a split's dY / X rows (re-read by the K workgroups of that split, which share an XCD) should fit
     // that XCD's 4 MiB L2; bounded slab size; at least enough workgroups to fill 256 CUs
     // 3 MiB of rows per split; 1.5 MiB measured faster in the 16-event micro-benchmark but slower in the 64-event step
     // (conv_bwd_weight 101.7 vs 97.4 ms; profiles/r02_conv_dw_knobs.log): tune at the benchmark's size
-    int64_t fit_kb = getenv("SEI_DW_FIT_KB") ? atoi(getenv("SEI_DW_FIT_KB")) : 3072;
+    int64_t fit_kb = 3072;
+#ifdef SEI_EXPERIMENTS
+    if (getenv("SEI_DW_FIT_KB")) fit_kb = atoi(getenv("SEI_DW_FIT_KB"));
+#endif
     int64_t rows_fit = (fit_kb << 10) / ((int64_t)(nIn + nOut) * 4);
     int tps = (int)(rows_fit / t.tile_rows);
     if (tps > DW_TILES_PER_ITER) tps = DW_TILES_PER_ITER;

@@ -433,8 +433,10 @@ static size_t fwd_lds(int tile_rows, int nOut, int slj, int K) {
     return ((size_t)tile_rows * (nOut + APAD) + 2 * 16 * slj * nOut) * sizeof(float) + (K + 1) * sizeof(int);
 }
 
-// SEI_FWD_PLAN="maxs,cs,slj,nOut,blocks[,waves][;...]" overrides the default tiling of the layers with that nOut
-// (kernel experiments only)
+#ifdef SEI_EXPERIMENTS
+// Kernel-experiment builds only (make EXTRA=-DSEI_EXPERIMENTS; tools/sweep_tile.py): SEI_FWD_PLAN=
+// "maxs,cs,slj,nOut,blocks[,waves][;...]" overrides the default tiling of the layers with that nOut.  The shipped library
+// holds the default plans only and reads no environment variable.
 static bool env_plan(int nOut, int *maxs, int *cs, int *slj, int *blocks, int *nw) {
     const char *e = getenv("SEI_FWD_PLAN");
     while (e && *e) {
@@ -452,6 +454,7 @@ static bool env_plan(int nOut, int *maxs, int *cs, int *slj, int *blocks, int *n
     }
     return false;
 }
+#endif
 
 static ConvPlan plan_tile(int nIn, int nOut, int K, int64_t n_dst) {
     ConvPlan p{};
@@ -486,6 +489,7 @@ static ConvPlan plan_tile(int nIn, int nOut, int K, int64_t n_dst) {
             // profiles/r02_conv_units_experiment.log); 192 columns (level 5, few tiles): slower, not used.
             p.nw = 8; p.maxs = 1; p.slj = 1; p.blocks = 2;
         }
+#ifdef SEI_EXPERIMENTS
         int em, ec, es, eb, ew;
         if (env_plan(nOut, &em, &ec, &es, &eb, &ew)) {
             if (tiles % ec == 0 && em >= 1 && em <= 4 && (ec == 1 || ec == 2)) {
@@ -496,6 +500,7 @@ static ConvPlan plan_tile(int nIn, int nOut, int K, int64_t n_dst) {
                 if (eb >= 1 && ec == 1 && tiles % eb == 0) p.blocks = eb;
             }
         }
+#endif
         p.nt = tiles / p.cs / p.blocks;
         p.tile_rows = 16 * p.maxs * (p.nw / p.cs);
         p.lds_bytes = fwd_lds(p.tile_rows, nOut / p.blocks, p.slj, K);
@@ -532,11 +537,17 @@ static int launch_mfma(const TiledRules &t, const ConvPlan &p, const float *X, c
 #define FWD_CASE(NT_, CS_, SLJ_, MAXS_)                                            \
     if (p.nt == NT_ && p.cs == CS_ && p.slj == SLJ_ && p.maxs == MAXS_ && p.nw == 4) \
         return launch_mfma<NT_, CS_, SLJ_, MAXS_>(t, p, X, W, bias, Y, nIn, init, stats, st);
+#ifdef SEI_EXPERIMENTS
 #define FWD_CASE8(NT_)                                                             \
     if (p.nt == NT_ && p.cs == 1 && p.maxs == 1 && p.nw == 8) {                    \
         if (p.slj == 2) return launch_mfma<NT_, 1, 2, 1, 8>(t, p, X, W, bias, Y, nIn, init, stats, st); \
         return launch_mfma<NT_, 1, 1, 1, 8>(t, p, X, W, bias, Y, nIn, init, stats, st);                 \
     }
+#else
+#define FWD_CASE8(NT_)                                                             \
+    if (p.nt == NT_ && p.cs == 1 && p.maxs == 1 && p.nw == 8 && p.slj == 1)        \
+        return launch_mfma<NT_, 1, 1, 1, 8>(t, p, X, W, bias, Y, nIn, init, stats, st);
+#endif
 #define FWD_CASE8C(NT_)                                                            \
     if (p.nt == NT_ && p.cs == 2 && p.maxs == 2 && p.nw == 8 && p.slj == 2)       \
         return launch_mfma<NT_, 2, 2, 2, 8>(t, p, X, W, bias, Y, nIn, init, stats, st);
@@ -571,9 +582,8 @@ int conv_forward(const TiledRules &t, const float *X, const float *W, const floa
     if (stats && (p.kind == 0 || t.n_sub == 0)) SEI_FAIL("conv_forward: statistics are only produced by the MFMA kernels");
     if (p.kind == 2) return conv_forward_wave(t, p, X, W, bias, Y, nIn, nOut, init, stats, st);
     if (p.kind == 1) {
-        // eight-wave workgroups (default for 96 columns; others through SEI_FWD_PLAN)
-        FWD_CASE8(2) FWD_CASE8(3) FWD_CASE8(4) FWD_CASE8(5) FWD_CASE8(6)
-        FWD_CASE8C(2) FWD_CASE8C(3) FWD_CASE8C(4) FWD_CASE8C(5)
+        // eight-wave workgroups: 96 / 128 / 160 columns in two column blocks
+        FWD_CASE8(3) FWD_CASE8(4) FWD_CASE8(5)
         // default plans
         FWD_BOTH_SLJ(1, 1, 2) FWD_BOTH_SLJ(2, 1, 2) FWD_BOTH_SLJ(3, 1, 2) FWD_BOTH_SLJ(4, 1, 2) FWD_BOTH_SLJ(5, 1, 2)
         FWD_BOTH_SLJ(6, 1, 2)
@@ -581,13 +591,15 @@ int conv_forward(const TiledRules &t, const float *X, const float *W, const floa
         FWD_BOTH_SLJ(6, 1, 1)
         FWD_BOTH_SLJ(7, 1, 1) FWD_BOTH_SLJ(8, 1, 1) FWD_BOTH_SLJ(9, 1, 1) FWD_BOTH_SLJ(10, 1, 1) FWD_BOTH_SLJ(11, 1, 1)
         FWD_BOTH_SLJ(12, 1, 1) FWD_BOTH_SLJ(13, 1, 1) FWD_BOTH_SLJ(14, 1, 1) FWD_BOTH_SLJ(15, 1, 1) FWD_BOTH_SLJ(16, 1, 1)
-        // alternates reachable through SEI_FWD_PLAN (kernel experiments)
+#ifdef SEI_EXPERIMENTS  // alternates reachable through SEI_FWD_PLAN
+        FWD_CASE8(2) FWD_CASE8(6) FWD_CASE8C(2) FWD_CASE8C(3) FWD_CASE8C(4) FWD_CASE8C(5)
         FWD_CASE(2, 1, 2, 4) FWD_CASE(4, 1, 2, 4) FWD_CASE(6, 1, 2, 4) FWD_CASE(2, 1, 1, 4) FWD_CASE(4, 1, 1, 4) FWD_CASE(6, 1, 1, 4)
         FWD_CASE(2, 1, 2, 1) FWD_CASE(4, 1, 2, 1) FWD_CASE(6, 1, 2, 1) FWD_CASE(2, 1, 2, 3) FWD_CASE(4, 1, 2, 3)
         FWD_CASE(4, 2, 2, 2) FWD_CASE(5, 2, 2, 2) FWD_CASE(6, 2, 2, 2) FWD_CASE(3, 2, 2, 2)
         FWD_CASE(4, 2, 2, 4) FWD_CASE(5, 2, 2, 4) FWD_CASE(6, 2, 2, 4) FWD_CASE(3, 2, 2, 4) FWD_CASE(2, 2, 2, 4) FWD_CASE(1, 2, 2, 4)
         FWD_CASE(3, 1, 2, 3) FWD_CASE(3, 1, 2, 4) FWD_CASE(5, 1, 2, 1) FWD_CASE(3, 1, 2, 1) FWD_CASE(5, 1, 1, 1) FWD_CASE(3, 1, 1, 1) FWD_CASE(1, 1, 2, 1) FWD_CASE(1, 1, 1, 1)
         FWD_CASE(8, 1, 2, 2) FWD_CASE(4, 2, 1, 2) FWD_CASE(5, 2, 1, 2) FWD_CASE(6, 2, 1, 2)
+#endif
         SEI_FAIL("conv_forward: no MFMA instantiation for this plan");
     }
     if (nIn <= 4 && (nOut == 16 || nOut == 32 || nOut == 64)) {

@@ -411,8 +411,9 @@ __global__ __launch_bounds__(64, wave_occ(NT, G)) void conv_wave_mfma_kernel(
     st.flush();
 }
 
-// SEI_WAVE_PLAN="nOut:NT,TR,G[;nOut:NT,TR,G...]" overrides the default tiling of the layers with that nOut
-// (kernel experiments only)
+#ifdef SEI_EXPERIMENTS
+// Kernel-experiment builds only (make EXTRA=-DSEI_EXPERIMENTS; tools/sweep_wave.py): SEI_WAVE_PLAN=
+// "nOut:NT,TR,G[;nOut:NT,TR,G...]" overrides the default tiling of the layers with that nOut.
 static bool env_wave_plan(int nOut, int *nt, int *tr, int *g) {
     const char *e = getenv("SEI_WAVE_PLAN");
     while (e && *e) {
@@ -428,18 +429,19 @@ static bool env_wave_plan(int nOut, int *nt, int *tr, int *g) {
 }
 
 static bool wave_instantiated(int nt, int g) { return nt >= 1 && nt <= 8 && (g == 2 || (g == 4 && nt <= 6) || (g == 3 && nt <= 8)); }
+#endif
 
 // Default use: the 32- and 64-column layers (levels 0-1 of the DUNE network).  There the workgroup-tile kernel's
 // phases hold too few sub-chunks to keep four lock-stepped waves busy (structural efficiency 0.24 / 0.55) and the
 // wave kernel measured +47 % / +10 % (profiles/r02_conv_wave_sweep1.log).  From 96 columns on, the B operands of
 // this kernel (4/MS bytes per lane and MFMA through the vector-memory path, MS ~ 1.7) saturate that path --
 // profiles/r02_conv_wave_diag_L2_C96.txt: half of a wave's time goes to ISSUING loads -- and the tile kernel, whose
-// weights are shared through LDS, wins.  SEI_CONV_KERNEL=wave|tile forces one kernel (experiments).
+// weights are shared through LDS, wins.  sei_debug_force_conv_kernel() pins one kernel (bit-identity tests, sweeps).
 bool plan_wave(int nIn, int nOut, int K, int64_t n_dst, ConvPlan *p) {
     if (nIn % 16 || nOut % 16 || nIn < 16 || nOut > 256 || K + 1 > 64) return false;
-    const char *kind = getenv("SEI_CONV_KERNEL");
-    if (kind && !strcmp(kind, "tile")) return false;
-    const bool forced = kind && !strcmp(kind, "wave");
+    const int kind = forced_conv_kernel();
+    if (kind != CONV_KERNEL_AUTO && kind != CONV_KERNEL_WAVE) return false;
+    const bool forced = kind == CONV_KERNEL_WAVE;
     const int tiles = nOut / 16;
     int nt = 0;
     for (int c = 8; c >= 1; c--)
@@ -448,10 +450,13 @@ bool plan_wave(int nIn, int nOut, int K, int64_t n_dst, ConvPlan *p) {
     int tr = 64, g = 2;
     if (nOut == 32) { tr = 128; g = 2; }
     if (nOut == 64) { tr = 64; g = 3; }
+    bool env = false;
+#ifdef SEI_EXPERIMENTS
     int en, et, eg;
-    const bool env = env_wave_plan(nOut, &en, &et, &eg) && en >= 1 && tiles % en == 0 &&
-                     (et == 64 || et == 128 || et == 192 || et == 256) && wave_instantiated(en, eg);
+    env = env_wave_plan(nOut, &en, &et, &eg) && en >= 1 && tiles % en == 0 &&
+          (et == 64 || et == 128 || et == 192 || et == 256) && wave_instantiated(en, eg);
     if (env) { nt = en; tr = et; g = eg; }
+#endif
     if (!forced && !env && nOut != 32 && nOut != 64) return false;
     if ((size_t)tr * nt * 16 * sizeof(float) > 64 * 1024) return false;
     p->kind = 2; p->tile_rows = tr; p->col_group = 0; p->blocks = tiles / nt; p->nt = nt; p->g = g;
@@ -475,9 +480,13 @@ static int launch_wave(const TiledRules &t, const ConvPlan &p, const float *X, c
 
 int conv_forward_wave(const TiledRules &t, const ConvPlan &p, const float *X, const float *W, const float *bias, float *Y,
                       int nIn, int nOut, const float *init, double *stats, hipStream_t st) {
+    // defaults (32 / 64 columns) and the forced-kernel plans (any column count, groups of 2)
     WAVE_CASE(1, 2) WAVE_CASE(2, 2) WAVE_CASE(3, 2) WAVE_CASE(4, 2) WAVE_CASE(5, 2) WAVE_CASE(6, 2) WAVE_CASE(7, 2) WAVE_CASE(8, 2)
-    WAVE_CASE(1, 3) WAVE_CASE(2, 3) WAVE_CASE(3, 3) WAVE_CASE(4, 3) WAVE_CASE(5, 3) WAVE_CASE(6, 3) WAVE_CASE(7, 3) WAVE_CASE(8, 3)
+    WAVE_CASE(4, 3)
+#ifdef SEI_EXPERIMENTS  // alternates reachable through SEI_WAVE_PLAN
+    WAVE_CASE(1, 3) WAVE_CASE(2, 3) WAVE_CASE(3, 3) WAVE_CASE(5, 3) WAVE_CASE(6, 3) WAVE_CASE(7, 3) WAVE_CASE(8, 3)
     WAVE_CASE(1, 4) WAVE_CASE(2, 4) WAVE_CASE(3, 4) WAVE_CASE(4, 4) WAVE_CASE(5, 4) WAVE_CASE(6, 4)
+#endif
     SEI_FAIL("conv_forward: no wave-kernel instantiation for this plan");
 }
 

@@ -3,6 +3,8 @@
 // HBM/MALL-bound integer work: one thread per point, coalesced reads of the COO array.
 #include "common.h"
 
+#include <hipcub/hipcub.hpp>
+
 namespace sei {
 
 // ------------------------------------------------------------------ exclusive scan (int32)
@@ -147,6 +149,11 @@ __global__ void input_rowof_kernel(const uint32_t *slot_of, const uint32_t *new_
     atomicAdd(&row_count[r], 1);
 }
 
+__global__ void iota_kernel(int32_t *out, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (int32_t)i;
+}
+
 static uint64_t table_capacity(int64_t n) {
     uint64_t cap = 1024;
     while (cap < (uint64_t)(2 * n + 1)) cap <<= 1;
@@ -222,6 +229,27 @@ int build_input_level(sei_metadata *m, const int32_t *coords, int64_t n, const i
     assign_rows_kernel<<<nb, T, 0, st>>>(coords, slot_of, lv->ht.vals, flag, n, lv->coords, new_vals, m->row_first);
     input_rowof_kernel<<<nb, T, 0, st>>>(slot_of, new_vals, n, m->input_row, m->row_last, m->row_count);
     SEI_LAUNCH_CHECK();
+    if (nr != n) {
+        // Several input points share a site (modes 3 / 4 sum them): their contributions are added in INPUT ORDER, not by
+        // float atomics.  dup_order = the point indices sorted by row with a STABLE radix sort (equal rows keep their input
+        // order), dup_start = exclusive scan of the rows' point counts: row r owns dup_order[dup_start[r] .. +row_count[r]).
+        // Batches without duplicates (every DUNE / SBND input) skip all of this.
+        int32_t *keys_in = m->input_row, *keys_out, *idx_in;
+        SEI_TRY(pool_alloc_t(&keys_out, n, st));
+        SEI_TRY(pool_alloc_t(&idx_in, n, st));
+        SEI_TRY(pool_alloc_t(&m->dup_order, n, st));
+        SEI_TRY(pool_alloc_t(&m->dup_start, nr + 1, st));
+        iota_kernel<<<nb, T, 0, st>>>(idx_in, n);
+        int bits = 1;
+        while ((1ll << bits) < nr + 1 && bits < 31) bits++;
+        size_t tmp_bytes = 0;
+        SEI_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys_in, keys_out, idx_in, m->dup_order, (int)n, 0, bits, st));
+        void *tmp = pool_alloc(tmp_bytes + 256, st);
+        if (!tmp) SEI_FAIL("device pool: out of memory");
+        SEI_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys_in, keys_out, idx_in, m->dup_order, (int)n, 0, bits, st));
+        SEI_TRY(exclusive_scan_i32(m->row_count, m->dup_start, nr, nullptr, st));
+        pool_free(tmp); pool_free(keys_out); pool_free(idx_in);
+    }
     // the table now maps key -> row
     pool_free(lv->ht.vals);
     lv->ht.vals = new_vals;
@@ -244,17 +272,32 @@ __global__ void input_feat_fwd_kernel(const float *__restrict__ in, int64_t n, i
     int r = input_row[i];
     float v = in[t];
     if (mode == 3 || mode == 4) {
-        int cnt = row_count[r];
-        if (mode == 4) v /= (float)cnt;
-        if (cnt == 1)
-            out[(int64_t)r * C + c] = v;
-        else
-            atomicAdd(&out[(int64_t)r * C + c], v);
+        // only reached when every row has ONE point (input_feat_sum_kernel otherwise)
+        out[(int64_t)r * C + c] = v;
     } else if (mode == 1) {
         if (row_last[r] == i) out[(int64_t)r * C + c] = v;
     } else {
         if (row_first[r] == i) out[(int64_t)r * C + c] = v;
     }
+}
+
+// modes 3 / 4 with duplicate input points: one thread per (row, channel) adds the row's points in input order
+// (dup_order: stable sort by row) -- a fixed summation order, bit-identical reruns like every other kernel.
+__global__ void input_feat_sum_kernel(const float *__restrict__ in, int64_t n_rows, int C, const int32_t *__restrict__ dup_order,
+                                      const int32_t *__restrict__ dup_start, const int32_t *__restrict__ row_count, int mode,
+                                      float *__restrict__ out) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_rows * C) return;
+    int64_t r = t / C;
+    int c = (int)(t - r * C);
+    const int cnt = row_count[r], s0 = dup_start[r];
+    float sum = 0.f;
+    for (int j = 0; j < cnt; j++) {
+        float v = in[(int64_t)dup_order[s0 + j] * C + c];
+        if (mode == 4) v /= (float)cnt;
+        sum = j == 0 ? v : sum + v;
+    }
+    out[t] = sum;
 }
 
 __global__ void input_feat_bwd_kernel(const float *__restrict__ dout, int64_t n, int C, const int32_t *input_row,
@@ -279,7 +322,13 @@ int input_features_fwd(sei_metadata *m, const float *in, int C, float *out, hipS
     if (m->levels.empty()) SEI_FAIL("InputLayer features: metadata has no input level");
     int64_t nr = m->levels[0]->n, n = m->n_input;
     if (nr == 0 || n == 0) return 0;
-    if (m->input_mode == 3 || m->input_mode == 4) SEI_HIP(hipMemsetAsync(out, 0, (size_t)nr * C * sizeof(float), st));
+    if ((m->input_mode == 3 || m->input_mode == 4) && m->dup_order) {
+        int64_t totr = nr * C;
+        input_feat_sum_kernel<<<(unsigned)((totr + 255) / 256), 256, 0, st>>>(in, nr, C, m->dup_order, m->dup_start, m->row_count,
+                                                                              m->input_mode, out);
+        SEI_LAUNCH_CHECK();
+        return 0;
+    }
     int64_t tot = n * C;
     input_feat_fwd_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, st>>>(in, n, C, m->input_row, m->row_first,
                                                                         m->row_last, m->row_count, m->input_mode, out);

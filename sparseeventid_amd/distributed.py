@@ -12,13 +12,15 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None):
+def init_from_env(backend=None, force=False):
     """Initialise the default process group from RANK / WORLD_SIZE / MASTER_* (torchrun contract).
-    Returns (rank, world, local_rank)."""
+    Returns (rank, world, local_rank).  A single process gets no group unless `force` is set: with a group, every
+    collective of the data-parallel path (gradient all-reduce, parameter / buffer broadcast) really runs through the
+    backend at world size 1 -- how the RCCL path is exercised on a one-GPU box."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -74,13 +76,13 @@ class FlatArena:
     def all_reduce_mean(self, start=0):
         """Sum gradients over ranks (RCCL all-reduce over xGMI), then scale by 1/world.  `start` > 0 skips the
         leading (frozen) part of the arena."""
-        if dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.is_initialized():   # also at world size 1: the collective runs (x * 1.0 is exact)
             g = self.grad[start:] if start else self.grad
             dist.all_reduce(g, op=dist.ReduceOp.SUM)
             g.mul_(1.0 / dist.get_world_size())
 
     def broadcast_parameters(self, src=0):
-        if dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.is_initialized():
             dist.broadcast(self.flat, src=src)
 
 
@@ -108,13 +110,13 @@ class FlatBuffers:
                 off += n
 
     def broadcast(self, src=0):
-        if self.flat is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        if self.flat is not None and dist.is_initialized():
             dist.broadcast(self.flat, src=src)
 
 
 def broadcast_buffers(modules, src=0):
     """What DDP's broadcast_buffers does for the BN running statistics."""
-    if not (dist.is_initialized() and dist.get_world_size() > 1):
+    if not dist.is_initialized():
         return
     for m in modules:
         for b in m.buffers():

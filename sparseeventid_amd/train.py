@@ -42,10 +42,11 @@ class WarmupFlatDecay:
 
 
 class Prefetched:
-    """An input batch whose InputLayer and rulebooks were built ahead of time on a side stream (Trainer.prefetch)."""
+    """An input batch whose InputLayer and rulebooks were built ahead of time on a side stream (Trainer.prefetch).
+    Holds the input tensors the side stream reads, so that a caller who drops the staged batch cannot free them early."""
 
-    def __init__(self, tensor, event):
-        self.tensor, self.event = tensor, event
+    def __init__(self, tensor, event, inputs=()):
+        self.tensor, self.event, self.inputs = tensor, event, inputs
 
 
 class Trainer:
@@ -119,11 +120,13 @@ class Trainer:
         return (c, f, bs), lab
 
     def prefetch(self, image):
-        """Builds the NEXT batch's InputLayer hash and every rulebook the last forward pass used, on a side stream,
-        while the current step is still computing (the reference builds them lazily inside the forward pass,
-        resnet.py:141-161 -> SCN Metadata).  Call it right after ``train_step`` returned -- the step's kernels are
-        queued, the rulebook kernels fill the gaps they leave -- and hand the result to the next ``train_step``.
-        Same kernels, same results (every kernel is deterministic); only WHEN the integer work runs changes."""
+        """Builds the NEXT batch's InputLayer hash and every rulebook the last forward pass used on a side stream, ahead
+        of the forward pass that needs them (the reference builds them lazily inside it, resnet.py:141-161 -> SCN
+        Metadata), and hands the result to the next ``train_step``.  Same kernels, same results (every kernel is
+        deterministic); only WHERE the integer work and its count read-backs run changes: off the main stream.  It does
+        NOT overlap with the step that is still computing: the side stream first waits for everything queued on the main
+        stream (pool blocks and input tensors are then safe to touch), and the build's read-backs block the host until
+        then -- measured 368 vs 370 ms per step."""
         if self.model == "sbnd" or isinstance(image, Prefetched) or not torch.cuda.is_available():
             return image
         if self._side is None:
@@ -132,15 +135,21 @@ class Trainer:
         # from here on the side stream may read the input tensors and reuse device-pool blocks that older batches
         # released: everything that used them was queued on the main stream before this point
         self._side.wait_stream(main)
+        inputs = tuple(x for x in image[:2] if isinstance(x, torch.Tensor) and x.is_cuda)
         with torch.cuda.stream(self._side):
             t = self.encoder.input_layer(image)
+            for x in inputs:
+                x.record_stream(self._side)   # read by the side stream's kernels: not reusable before they are done
             try:
                 t.metadata.prebuild_like(self._template)
-            except RuntimeError:
-                pass  # a level of the template does not exist for this batch: the forward builds lazily
+            except RuntimeError as e:
+                # a level of the template does not exist for this batch (tiny event): the forward builds lazily.
+                # Anything else (out of memory, hash table full) is a real failure.
+                if "no level with this spatial size" not in str(e) and "smaller than filter" not in str(e):
+                    raise
             ev = torch.cuda.Event()
             ev.record(self._side)
-        return Prefetched(t, ev)
+        return Prefetched(t, ev, inputs)
 
     def forward(self, image):
         if self.model != "sbnd":
@@ -196,7 +205,8 @@ class Trainer:
         import os
         os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
         torch.save({"state_dict": {k: v.detach().cpu() for k, v in self.state_dict().items()},
-                    "global_step": self.global_step, "optimizer": self.opt.state_dict()}, path)
+                    "global_step": self.global_step, "optimizer": self.opt.state_dict(),
+                    "opt_start": self.opt_start, "arena_numel": int(self.arena.numel)}, path)
 
     def _load_into(self, module, prefix, state):
         sub = {k[len(prefix):]: v for k, v in state.items() if k.startswith(prefix)}
@@ -219,6 +229,16 @@ class Trainer:
         if resume:
             self.global_step = int(ck.get("global_step", 0))
             if "optimizer" in ck:
+                # the optimizer state belongs to ONE flat parameter = arena[opt_start:]: a checkpoint written with another
+                # arena layout (alignment padding, a frozen encoder) must not be loaded into it silently
+                want = int(self.flat_param.numel())
+                for st in ck["optimizer"].get("state", {}).values():
+                    for k in ("exp_avg", "exp_avg_sq"):
+                        if k in st and int(st[k].numel()) != want:
+                            raise ValueError("checkpoint optimizer state has %d elements, this trainer optimises %d "
+                                             "(arena layout / frozen-encoder setting differ: saved opt_start=%s, here %d); "
+                                             "load with resume=False to take the weights only"
+                                             % (int(st[k].numel()), want, ck.get("opt_start", "?"), self.opt_start))
                 self.opt.load_state_dict(ck["optimizer"])
                 self.flat_param.grad = self.arena.grad[self.opt_start:]
             elif "optimizer_states" in ck:

@@ -20,3 +20,18 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+CONV_KERNELS = {"default": 0, "tile": 1, "wave": 2, "band": 3}
+
+
+@pytest.fixture
+def force_conv_kernel():
+    """force_conv_kernel("tile" | "wave" | "band" | "default"): pins the forward / dX kernel family
+    (sei_debug_force_conv_kernel) for the test and restores the plan's own choice afterwards."""
+    from sparseeventid_amd._lib import lib
+
+    def force(kind):
+        assert lib().sei_debug_force_conv_kernel(CONV_KERNELS[kind]) == 0
+    yield force
+    lib().sei_debug_force_conv_kernel(0)

@@ -72,3 +72,35 @@ def test_two_rank_gloo_gradient_allreduce():
         assert p.exitcode == 0
     res = dict(q.get(timeout=5) for _ in range(2))
     assert abs(res[0] - res[1]) < 1e-6
+
+
+def _solo_worker(port, out):
+    """world size 1 with a forced group: every collective of the exchange step still goes through the backend."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    from sparseeventid_amd.distributed import FlatArena, FlatBuffers, init_from_env
+    assert init_from_env("gloo")[:2] == (0, 1) and not dist.is_initialized()      # no group unless forced
+    assert init_from_env("gloo", force=True)[:2] == (0, 1) and dist.is_initialized()
+    calls = []
+    real_ar, real_bc = dist.all_reduce, dist.broadcast
+    dist.all_reduce = lambda *a, **k: (calls.append("ar"), real_ar(*a, **k))[1]
+    dist.broadcast = lambda *a, **k: (calls.append("bc"), real_bc(*a, **k))[1]
+    net = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.BatchNorm1d(3))
+    arena, fb = FlatArena([net]), FlatBuffers([net])
+    arena.broadcast_parameters(0)
+    fb.broadcast(0)
+    arena.zero_grad()
+    net(torch.randn(5, 4)).sum().backward()
+    g = arena.grad.clone()
+    arena.all_reduce_mean()
+    assert torch.equal(g, arena.grad) and calls == ["bc", "bc", "ar"]
+    out.put("ok")
+    dist.destroy_process_group()
+
+
+def test_single_rank_forced_group_runs_the_collectives():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_solo_worker, args=(_free_port(), q))
+    p.start()
+    p.join(120)
+    assert p.exitcode == 0 and q.get(timeout=5) == "ok"

@@ -65,6 +65,11 @@ def test_default_network_full_size_events_match_oracle():
     for k in HEADS:
         assert rel_err(logits[k], logits64[k]) < 1e-4, k
         assert rel_err(logits[k], ologits[k]) < 1e-4, k
+        # and element-wise (|a - b| <= 1e-4 |b| + 1e-6): every logit, not only the largest one
+        a, b = logits[k].detach().cpu().double(), ologits[k].detach().double()
+        assert bool(((a - b).abs() <= 1e-4 * b.abs() + 1e-6).all()), (k, float(((a - b).abs() / b.abs().clamp_min(1e-6)).max()))
+        b64 = logits64[k].detach()
+        assert bool(((a - b64).abs() <= 1e-4 * b64.abs() + 1e-6).all()), k
     assert abs(float(loss.detach()) - float(oloss.detach())) < 1e-4 * max(1.0, abs(float(oloss.detach())))
 
     named = dict(enc.named_parameters())

@@ -127,15 +127,15 @@ CONV_CASES = [(1, 32, [5, 5, 5]), (32, 32, [3, 3, 3]), (64, 64, [3, 3, 3]), (96,
               (256, 208, [1, 3, 3])]
 
 
-@pytest.mark.parametrize("kernel", ["default", "tile", "wave"])
+@pytest.mark.parametrize("kernel", ["default", "tile", "wave", "band"])
 @pytest.mark.parametrize("ci,co,filt", CONV_CASES)
-def test_subm_conv_forward_backward(ci, co, filt, kernel, monkeypatch):
-    """`kernel` forces the workgroup-tile or the wave-private MFMA kernel (the library reads SEI_CONV_KERNEL per call)
-    so that both stay covered for every plane count whatever the default plan picks."""
+def test_subm_conv_forward_backward(ci, co, filt, kernel, force_conv_kernel):
+    """`kernel` forces the workgroup-tile, the wave-private or the row-band MFMA kernel (sei_debug_force_conv_kernel)
+    so that all three stay covered for every plane count whatever the default plan picks."""
     if kernel != "default":
         if ci % 16 or co % 16:
             pytest.skip("scalar kernels: no MFMA variant to force")
-        monkeypatch.setenv("SEI_CONV_KERNEL", kernel)
+        force_conv_kernel(kernel)
     scn = _engine()
     sp, B = [14, 12, 16], 2
     coords, feats = blob_cloud(21, B, sp, 260, ci)
@@ -159,14 +159,14 @@ def test_subm_conv_forward_backward(ci, co, filt, kernel, monkeypatch):
     assert rel_err(f.grad, fo.grad) < TOL
 
 
-@pytest.mark.parametrize("kernel", ["default", "tile", "wave"])
+@pytest.mark.parametrize("kernel", ["default", "tile", "wave", "band"])
 @pytest.mark.parametrize("ci,co,size", [(32, 64, [2, 2, 2]), (64, 96, [2, 2, 2]), (160, 192, [2, 2, 2]),
                                         (16, 32, [1, 2, 2]), (5, 7, [2, 2, 2]), (32, 32, [3, 3, 3])])
-def test_strided_conv_forward_backward(ci, co, size, kernel, monkeypatch):
+def test_strided_conv_forward_backward(ci, co, size, kernel, force_conv_kernel):
     if kernel != "default":
         if ci % 16 or co % 16:
             pytest.skip("scalar kernels: no MFMA variant to force")
-        monkeypatch.setenv("SEI_CONV_KERNEL", kernel)
+        force_conv_kernel(kernel)
     scn = _engine()
     sp, B = [15, 12, 18], 2
     if size[0] == 1:

@@ -99,8 +99,8 @@ def test_training_with_prefetch_is_bit_identical_to_lazy_training():
         assert torch.equal(a, b), k
 
 
-def test_two_stream_backward_is_bit_identical(monkeypatch):
-    """SEI_BWD_STREAMS=1: dW of every layer on the library's side stream next to dX (sei_conv_backward) -- same kernels,
+def test_two_stream_backward_is_bit_identical():
+    """sei_set_backward_streams(1): dW of every layer on the library's side stream next to dX (sei_conv_backward) -- same kernels,
     same results; also together with the prefetch."""
     base, over = _trainer(), _trainer()
     batches = _batches(base)
@@ -108,13 +108,17 @@ def test_two_stream_backward_is_bit_identical(monkeypatch):
     torch.manual_seed(77)
     for i in order:
         base.train_step(*batches[i])
-    monkeypatch.setenv("SEI_BWD_STREAMS", "1")
-    torch.manual_seed(77)
-    staged = over.prefetch(batches[order[0]][0])
-    for j, i in enumerate(order):
-        over.train_step(staged, batches[i][1])
-        if j + 1 < len(order):
-            staged = over.prefetch(batches[order[j + 1]][0])
-    torch.cuda.synchronize()
+    from sparseeventid_amd._lib import lib
+    assert lib().sei_set_backward_streams(1) == 0
+    try:
+        torch.manual_seed(77)
+        staged = over.prefetch(batches[order[0]][0])
+        for j, i in enumerate(order):
+            over.train_step(staged, batches[i][1])
+            if j + 1 < len(order):
+                staged = over.prefetch(batches[order[j + 1]][0])
+        torch.cuda.synchronize()
+    finally:
+        lib().sei_set_backward_streams(0)
     assert torch.equal(base.arena.flat, over.arena.flat)
 

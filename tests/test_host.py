@@ -150,6 +150,17 @@ def test_checkpoint_roundtrip_and_encoder_only_restore(tmp_path):
     torch.save(bad, str(tmp_path / "bad.ckpt"))
     with pytest.raises(ValueError):
         b.load_checkpoint(str(tmp_path / "bad.ckpt"))
+    # optimizer state of another arena layout (here: the frozen-encoder trainer optimises arena[start:]) is refused with a
+    # clear error instead of corrupting fused Adam at the first step (advisor finding, round 2)
+    for p in a.head.parameters():
+        p.grad.normal_()
+    a.opt.step()                                   # gives Adam exp_avg / exp_avg_sq of the whole arena
+    a.save_checkpoint(str(tmp_path / "stepped.ckpt"))
+    assert torch.load(str(tmp_path / "stepped.ckpt"))["opt_start"] == 0
+    with pytest.raises(ValueError, match="optimizer state"):
+        c.load_checkpoint(str(tmp_path / "stepped.ckpt"))
+    c.load_checkpoint(str(tmp_path / "stepped.ckpt"), resume=False)      # weights only: fine
+    b.load_checkpoint(str(tmp_path / "stepped.ckpt"))                    # same layout: fine
     lit = {"state_dict": ck["state_dict"], "global_step": 5, "optimizer_states": [{}], "lr_schedulers": []}
     torch.save(lit, str(tmp_path / "lit.ckpt"))
     with pytest.warns(UserWarning):
