@@ -130,6 +130,9 @@ int sei_set_backward_streams(int32_t on);
  * (0 = the plan picks (default), 1 = workgroup-tile kernel, 2 = wave-private kernel, 3 = row-band kernel).  The
  * families produce bit-identical results (same per-row summation order); tests/test_gpu_kernels_agree.py asserts it. */
 int sei_debug_force_conv_kernel(int32_t kind);
+/* The row-band kernel's loader / compute waves hand weight slices over through LDS words they poll; every poll loop is
+ * bounded, and a loop that ran out (it never should) is counted here instead of hanging the GPU.  Synchronises the device. */
+int sei_debug_band_timeouts(int32_t *count, int32_t reset);
 
 /* ---- BatchNormalization (+fused LeakyReLU, +fused residual AddTable)
  *      (scn.BatchNormalization / BatchNormLeakyReLU / BatchNormReLU + scn.AddTable + scn.LeakyReLU;

@@ -569,7 +569,7 @@ static int conv_forward_impl(sei_rulebook_t *rb, const float *X, const float *W,
     }
     const int kind = nIn == 32 && nOut == 32 ? PROF_CONV_FWD_C32 : PROF_CONV_FWD;
     if (p.kind != 1) {  // natural weight layout: no copy
-        if (p.kind == 2) {
+        if (p.kind >= 2) {
             SEI_TRY(aw.stage(W, (size_t)t->K * nIn * nOut, st));
             W = aw.p;
         }

@@ -220,7 +220,8 @@ int export_rules(const TiledRules &t, int64_t *start_host, int32_t *rin, int32_t
 // counts, the filter volume of the rulebook and the dst row count, and threaded through rulebook build, weight
 // transform and launch.
 struct ConvPlan {
-    int kind = 0;        // 0 scalar tile kernels (tiny / odd plane counts), 1 workgroup-tile MFMA kernel, 2 wave-private MFMA kernel
+    int kind = 0;        // 0 scalar tile kernels (tiny / odd plane counts), 1 workgroup-tile MFMA kernel, 2 wave-private MFMA kernel,
+                         // 3 row-band MFMA kernel (nw = compute waves per workgroup, g = ring depth in slices)
     int tile_rows = 0;   // rulebook variant (dst rows per tile)
     int col_group = 0;   // kind 1: width of the column groups whose columns are stored permuted (0 = natural layout)
     int blocks = 1;      // column blocks (kind 1: weights stored as [block][K][nIn][nOut/blocks])
@@ -234,12 +235,15 @@ ConvPlan plan_conv(int nIn, int nOut, int K, int64_t n_dst);
 enum { CONV_KERNEL_AUTO = 0, CONV_KERNEL_TILE = 1, CONV_KERNEL_WAVE = 2, CONV_KERNEL_BAND = 3 };
 int forced_conv_kernel();
 bool plan_wave(int nIn, int nOut, int K, int64_t n_dst, ConvPlan *p);
+bool plan_band(int nIn, int nOut, int K, int64_t n_dst, ConvPlan *p);
 // stats (optional, MFMA kernels only): per-(tile, part) column sums of the OUTPUT rows, [n_parts][2][nOut] doubles
 // (sum, sum of squares) accumulated in the kernel epilogue from the LDS tile -- BatchNorm statistics without a second
 // read of the conv output.  conv_stats_parts() = how many parts this plan writes (0: the plan cannot).
 int conv_forward(const TiledRules &t, const float *X, const float *W, const float *bias, float *Y, int nIn, int nOut,
                  hipStream_t st, const float *init = nullptr, double *stats = nullptr);
 int conv_forward_wave(const TiledRules &t, const ConvPlan &p, const float *X, const float *W, const float *bias, float *Y,
+                      int nIn, int nOut, const float *init, double *stats, hipStream_t st);
+int conv_forward_band(const TiledRules &t, const ConvPlan &p, const float *X, const float *W, const float *bias, float *Y,
                       int nIn, int nOut, const float *init, double *stats, hipStream_t st);
 int64_t conv_stats_parts(const ConvPlan &p, const TiledRules &t);
 // Wout[k][r][perm(c)]: transpose=false: rows=nIn, cols=nOut (forward); transpose=true: Wout[k][co][perm(ci)] = W[ks][ci][co]

@@ -519,6 +519,7 @@ static ConvPlan plan_tile(int nIn, int nOut, int K, int64_t n_dst) {
 // the plan of one convolution call (forward, or dX with the plane counts swapped)
 ConvPlan plan_conv(int nIn, int nOut, int K, int64_t n_dst) {
     ConvPlan p{};
+    if (plan_band(nIn, nOut, K, n_dst, &p)) return p;
     if (plan_wave(nIn, nOut, K, n_dst, &p)) return p;
     return plan_tile(nIn, nOut, K, n_dst);
 }
@@ -559,7 +560,7 @@ int64_t conv_stats_parts(const ConvPlan &p, const TiledRules &t) {
         const int cout = p.nt * p.cs * 16;
         return (int64_t)t.n_tiles * (256 / cout > 0 ? 256 / cout : 1);
     }
-    if (p.kind == 2) {
+    if (p.kind == 2 || p.kind == 3) {
         const int nc = p.nt * 16;
         return (int64_t)t.n_tiles * (64 / nc > 0 ? 64 / nc : 1);
     }
@@ -581,6 +582,7 @@ int conv_forward(const TiledRules &t, const float *X, const float *W, const floa
     if (p.tile_rows != t.tile_rows) SEI_FAIL("conv_forward: rulebook tile size does not match the kernel plan");
     if (stats && (p.kind == 0 || t.n_sub == 0)) SEI_FAIL("conv_forward: statistics are only produced by the MFMA kernels");
     if (p.kind == 2) return conv_forward_wave(t, p, X, W, bias, Y, nIn, nOut, init, stats, st);
+    if (p.kind == 3) return conv_forward_band(t, p, X, W, bias, Y, nIn, nOut, init, stats, st);
     if (p.kind == 1) {
         // eight-wave workgroups: 96 / 128 / 160 columns in two column blocks
         FWD_CASE8(3) FWD_CASE8(4) FWD_CASE8(5)

@@ -23,13 +23,12 @@
 // other, and the per-phase barrier, zero-init and weight-staging costs are gone.
 #include "common.h"
 #include "conv_tile.h"
+#include "conv_rows.h"
 
 #include <stdlib.h>
 #include <string.h>
 
 namespace sei {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // Diagnostic builds only (make EXTRA="-DSEI_STAMPS" / EXTRA="-DSEI_WAVE_ABL=n"; tools/wave_diag.sh): every wave adds
 // the s_memtime ticks it spends in each part of the kernel to g_wstamps; the ablation bits remove one cost at a time
@@ -71,74 +70,6 @@ struct WStamp {
 
 __device__ __forceinline__ f32x4 wmfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-}
-
-// Unconditional load of a clamped row, and NO select: a padding slot (src < 0) reads row 0 and its products are
-// garbage, but an MFMA output row depends on its own A row only and padding slots are never written back (wrmw).
-// (A select on the loaded value would make hipcc wait for the gather right where it is issued.)
-__device__ __forceinline__ float4 wload_a(const float *__restrict__ X, int src, int CIN, int off) {
-    uint32_t row = (uint32_t)(src > 0 ? src : 0);
-    if (SEI_WAVE_ABL & 1) row &= 1023u;
-    return *reinterpret_cast<const float4 *>(X + (uint64_t)row * (uint32_t)CIN + off);
-}
-
-// B operands of one input plane for the NT column tiles: column tile 4q+j at lane r16 is column 64q + 4*r16 + j
-// (remainder tiles: pairs at 2*r16 + j, a single tile at r16) of the wave's column block -- wide loads from W's
-// natural row-major layout.
-template <int NT>
-__device__ __forceinline__ void wload_b(const float *__restrict__ wrow, int r16, float (&b)[NT]) {
-    constexpr int B4 = NT / 4, REM = NT % 4;
-#pragma unroll
-    for (int q = 0; q < B4; q++) {
-        const float4 v = *reinterpret_cast<const float4 *>(wrow + 64 * q + 4 * r16);
-        b[4 * q + 0] = v.x; b[4 * q + 1] = v.y; b[4 * q + 2] = v.z; b[4 * q + 3] = v.w;
-    }
-    if (REM >= 2) {
-        const float2 v = *reinterpret_cast<const float2 *>(wrow + 64 * B4 + 2 * r16);
-        b[4 * B4 + 0] = v.x; b[4 * B4 + 1] = v.y;
-    }
-    if (REM == 1) b[4 * B4] = wrow[64 * B4 + r16];
-    if (REM == 3) b[4 * B4 + 2] = wrow[64 * B4 + 32 + r16];
-}
-
-// tile[dst rows of the sub-chunk] += partial sums.  D[row = 4g+i][col tile n] of lane (g, r16) belongs to rule slot
-// 4g+i; slots [0, nv) are rules (padding sits at the end of a sub-chunk and must not write: its dst is row 0).
-// All reads are issued before the adds.
-template <int NT>
-__device__ __forceinline__ void wrmw(float *acc_tile, int AS, uint32_t d4, int nv, int g, int r16,
-                                     const f32x4 (&acc)[NT]) {
-    constexpr int B4 = NT / 4, REM = NT % 4;
-    float4 t4[4][B4 > 0 ? B4 : 1];
-    float2 t2[4];
-    float t1[4];
-    float *base[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        base[i] = acc_tile + ((d4 >> (8 * i)) & 0xFF) * AS;
-#pragma unroll
-        for (int q = 0; q < B4; q++) t4[i][q] = *reinterpret_cast<const float4 *>(base[i] + 64 * q + 4 * r16);
-        if (REM >= 2) t2[i] = *reinterpret_cast<const float2 *>(base[i] + 64 * B4 + 2 * r16);
-        if (REM == 1) t1[i] = base[i][64 * B4 + r16];
-        if (REM == 3) t1[i] = base[i][64 * B4 + 32 + r16];
-    }
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        if (4 * g + i < nv) {
-#pragma unroll
-            for (int q = 0; q < B4; q++) {
-                float4 v = t4[i][q];
-                v.x += acc[4 * q + 0][i]; v.y += acc[4 * q + 1][i]; v.z += acc[4 * q + 2][i]; v.w += acc[4 * q + 3][i];
-                *reinterpret_cast<float4 *>(base[i] + 64 * q + 4 * r16) = v;
-            }
-            if (REM >= 2) {
-                float2 v = t2[i];
-                v.x += acc[4 * B4 + 0][i]; v.y += acc[4 * B4 + 1][i];
-                *reinterpret_cast<float2 *>(base[i] + 64 * B4 + 2 * r16) = v;
-            }
-            if (REM == 1) base[i][64 * B4 + r16] = t1[i] + acc[4 * B4][i];
-            if (REM == 3) base[i][64 * B4 + 32 + r16] = t1[i] + acc[4 * B4 + 2][i];
-        }
-    }
 }
 
 template <int G>
@@ -184,7 +115,7 @@ __device__ __forceinline__ void wprefetch(const float *__restrict__ X, const flo
     // CU's address path ~1 KiB of its ~20-30 B/clk, used or not
 #pragma unroll
     for (int m = 0; m < G; m++)
-        if (m == 0 || m < cnt) a[m] = wload_a(X, rows[m], CIN, 16 * j + 4 * g);
+        if (m == 0 || m < cnt) a[m] = wload_a<SEI_WAVE_ABL>(X, rows[m], CIN, 16 * j + 4 * g);
     const float *wn = (SEI_WAVE_ABL & 2) ? wl : wl + ((size_t)k * CIN + 16 * j) * ldy;
 #pragma unroll
     for (int e = 0; e < 4; e++) wload_b<NT>(wn + (size_t)e * ldy, r16, b[e]);

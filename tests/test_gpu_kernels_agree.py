@@ -1,0 +1,114 @@
+"""GPU: the three forward / dX kernel families -- workgroup-tile (conv_fwd.hip), wave-private (conv_wave.hip) and row-band
+(conv_band.hip: row-band ownership + LDS weight ring filled by a loader wave) -- keep the SAME per-row summation order
+(offsets ascending; inside an offset one MFMA chain over the input planes, then tile += partial), so their results are
+bit-identical: forward, dX, dX with the skip gradient folded in, and the BatchNorm statistics of the epilogue.  The
+row-band kernel's bounded poll loops must never run out (sei_debug_band_timeouts)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from tests.util import blob_cloud
+
+pytestmark = pytest.mark.gpu
+FAMILIES = ("tile", "wave", "band")
+
+
+def _timeouts(reset=False):
+    from sparseeventid_amd._lib import lib
+    n = ctypes.c_int32()
+    assert lib().sei_debug_band_timeouts(ctypes.byref(n), 1 if reset else 0) == 0
+    return n.value
+
+
+def _cloud(seed, B, sp, n):
+    import sparseeventid_amd.scn as scn
+    coords, feats = blob_cloud(seed, B, sp, n, 1)
+    t = scn.InputLayer(3, sp)((torch.from_numpy(coords), torch.from_numpy(feats).cuda(), B))
+    return t
+
+
+@pytest.mark.parametrize("ci,co,filt,rows", [(96, 96, [3, 3, 3], 3000), (128, 128, [3, 3, 3], 1500), (160, 160, [3, 3, 3], 900),
+                                             (192, 192, [3, 3, 3], 700), (64, 64, [3, 3, 3], 2500), (32, 32, [3, 3, 3], 2500),
+                                             (192, 128, [1, 1, 1], 900), (96, 128, [3, 3, 3], 1100), (48, 80, [1, 3, 3], 800),
+                                             (32, 96, [3, 3, 3], 1300), (224, 224, [3, 3, 3], 500), (16, 16, [5, 5, 1], 600)])
+def test_kernel_families_bit_identical(ci, co, filt, rows, force_conv_kernel):
+    import sparseeventid_amd.scn as scn
+    _timeouts(reset=True)
+    sp, B = [26, 22, 24], 3
+    t = _cloud(31 + ci, B, sp, rows)
+    n = t.features.shape[0]
+    assert n % 64 != 0                      # a partial last band
+    gen = torch.Generator(device="cuda").manual_seed(ci * 1000 + co)
+    x = torch.randn(n, ci, device="cuda", generator=gen)
+    gy = torch.randn(n, co, device="cuda", generator=gen)
+    conv = scn.SubmanifoldConvolution(3, ci, co, filt, True).cuda()
+    with torch.no_grad():
+        conv.bias.normal_()
+    res = {}
+    for fam in FAMILIES:
+        force_conv_kernel(fam)
+        xx = x.clone().requires_grad_(True)
+        y = conv(scn.SparseConvNetTensor(xx, t.metadata, t.spatial_size)).features
+        conv.weight.grad = None
+        y.backward(gy)
+        res[fam] = (y.detach().clone(), xx.grad.clone(), conv.weight.grad.clone())
+    for fam in FAMILIES[1:]:
+        for a, b, what in zip(res[FAMILIES[0]], res[fam], ("forward", "dX", "dW")):
+            assert torch.equal(a, b), (fam, what)
+    assert _timeouts() == 0
+
+
+def test_fused_residual_block_bit_identical_across_families(force_conv_kernel):
+    """conv -> BN (statistics from the conv epilogue) -> act -> conv -> BN -> +x -> act, and its backward with the skip
+    gradient seeding the dX accumulators: one autograd node, three kernel families, identical bits."""
+    import sparseeventid_amd.scn as scn
+    from sparseeventid_amd.networks import ResidualBlock
+    from sparseeventid_amd.config import Encoder
+    _timeouts(reset=True)
+    sp, B, C = [30, 28, 26], 2, 96
+    t = _cloud(77, B, sp, 2600)
+    n = t.features.shape[0]
+    torch.manual_seed(3)
+    blk = ResidualBlock(nIn=C, nOut=C, dim=3, params=Encoder()).cuda().train()
+    x = torch.randn(n, C, device="cuda")
+    gy = torch.randn(n, C, device="cuda")
+    res = {}
+    for fam in FAMILIES:
+        force_conv_kernel(fam)
+        sd = {k: v.clone() for k, v in blk.state_dict().items()}
+        for p in blk.parameters():
+            p.grad = None
+        xx = x.clone().requires_grad_(True)
+        y = blk(scn.SparseConvNetTensor(xx, t.metadata, t.spatial_size)).features
+        y.backward(gy)
+        res[fam] = [y.detach().clone(), xx.grad.clone()] + [p.grad.clone() for p in blk.parameters()] + \
+                   [b.clone() for b in blk.buffers()]
+        blk.load_state_dict(sd)
+    for fam in FAMILIES[1:]:
+        for i, (a, b) in enumerate(zip(res[FAMILIES[0]], res[fam])):
+            assert torch.equal(a, b), (fam, i)
+    assert _timeouts() == 0
+
+
+def test_band_kernel_strided_and_transposed_rules(force_conv_kernel):
+    """scn.Convolution 2^3 / stride 2 (forward rules) and its dX (transposed rulebook) through the row-band kernel."""
+    import sparseeventid_amd.scn as scn
+    _timeouts(reset=True)
+    sp, B = [31, 29, 33], 2
+    t = _cloud(91, B, sp, 3000)
+    n = t.features.shape[0]
+    x = torch.randn(n, 96, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    conv = scn.Convolution(3, 96, 128, 2, 2, False).cuda()
+    res = {}
+    for fam in FAMILIES:
+        force_conv_kernel(fam)
+        xx = x.clone().requires_grad_(True)
+        y = conv(scn.SparseConvNetTensor(xx, t.metadata, t.spatial_size)).features
+        g = torch.Generator(device="cuda").manual_seed(2)
+        y.backward(torch.randn(y.shape, device="cuda", generator=g))
+        res[fam] = (y.detach().clone(), xx.grad.clone())
+    for fam in FAMILIES[1:]:
+        assert torch.equal(res["tile"][0], res[fam][0]) and torch.equal(res["tile"][1], res[fam][1]), fam
+    assert _timeouts() == 0
