@@ -560,6 +560,10 @@ int64_t conv_stats_parts(const ConvPlan &p, const TiledRules &t) {
         const int cout = p.nt * p.cs * 16;
         return (int64_t)t.n_tiles * (256 / cout > 0 ? 256 / cout : 1);
     }
+    if (p.kind == 3 && p.cs) {  // shared-tile ring kernel: the workgroup-tile epilogue (conv_tile.h: tile_stats)
+        const int cout = p.nt * 16;
+        return (int64_t)t.n_tiles * (256 / cout > 0 ? 256 / cout : 1);
+    }
     if (p.kind == 2 || p.kind == 3) {
         const int nc = p.nt * 16;
         return (int64_t)t.n_tiles * (64 / nc > 0 ? 64 / nc : 1);

@@ -16,6 +16,7 @@ template <int ABL = 0>
 __device__ __forceinline__ float4 wload_a(const float *__restrict__ X, int src, int CIN, int off) {
     uint32_t row = (uint32_t)(src > 0 ? src : 0);
     if (ABL & 1) row &= 1023u;
+    if (ABL & 32) return make_float4(1.f + row, 2.f, 3.f + off, 4.f);  // diagnostic: no gather at all
     return *reinterpret_cast<const float4 *>(X + (uint64_t)row * (uint32_t)CIN + off);
 }
 
