@@ -74,9 +74,11 @@ int sei_batch_size(sei_metadata_t *m, int32_t *batch_size);
 
 /* Builds in `m` (which must already hold its input level) every rulebook, and every tiled variant of it, that the
  * metadata `like` of an EARLIER batch holds -- same filter geometry, this batch's coordinates.  The reference builds
- * rule books lazily inside the forward pass (SCN Metadata::getSubmanifoldRuleBook / getRuleBook); a training loop that
- * knows its next batch can call this on a side stream while the current step computes, and the forward then finds
- * everything built.  Fails like the lazy path would if a level of `like` does not exist for this batch. */
+ * rule books lazily inside the forward pass (SCN Metadata::getSubmanifoldRuleBook / getRuleBook), and so does this
+ * library by default, with one count read-back (stream synchronisation) per tiled variant, also in the backward pass.
+ * Here all variants are begun back to back and share ONE read-back (plus one per new strided level), so the forward and
+ * backward passes that follow synchronise nothing.  May run on the caller's main stream at the top of the forward pass, or
+ * on a side stream ahead of it.  Fails like the lazy path would if a level of `like` does not exist for this batch. */
 int sei_metadata_prebuild_like(sei_metadata_t *m, sei_metadata_t *like, sei_stream_t stream);
 
 /* ---- rulebooks (SCN `getSubmanifoldRuleBook` / `getRuleBook`) ---------------------------- */
@@ -199,6 +201,11 @@ int sei_prof_enable(int32_t on);
 int sei_prof_reset(void);
 /* Synchronises outstanding events.  out = {launches, total_ms, algorithmic flops, algorithmic bytes} */
 int sei_prof_query(int32_t kind, double out[4]);
+
+/* number of stream synchronisations (count read-backs) the library has performed since the last reset: one for the
+ * InputLayer, one per new strided level, one per lazily built tiled rule variant -- or ONE for all the variants that
+ * sei_metadata_prebuild_like builds */
+int sei_debug_sync_count(int64_t *count, int32_t reset);
 
 /* library-owned device memory (rulebooks, scratch): bytes currently held by the pool */
 int sei_pool_stats(int64_t *bytes_held, int64_t *bytes_in_use);

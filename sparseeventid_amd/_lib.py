@@ -62,6 +62,7 @@ _SIGNATURES = {
     "sei_prof_enable": (ctypes.c_int, [ctypes.c_int32]),
     "sei_prof_reset": (ctypes.c_int, []),
     "sei_prof_query": (ctypes.c_int, [ctypes.c_int32, ctypes.POINTER(ctypes.c_double)]),
+    "sei_debug_sync_count": (ctypes.c_int, [c_i64p, ctypes.c_int32]),
     "sei_pool_stats": (ctypes.c_int, [c_i64p, c_i64p]),
     "sei_pool_trim": (ctypes.c_int, []),
 }

@@ -201,6 +201,12 @@ void pool_fence_end(PoolFence fence) {
     }
 }
 
+static std::atomic<long long> g_sync_count{0};
+hipError_t sync_stream(hipStream_t st) {
+    g_sync_count.fetch_add(1, std::memory_order_relaxed);
+    return hipStreamSynchronize(st);
+}
+
 int ensure_max_lds(const void *kernel, int bytes) {
     static std::mutex mu;
     static std::map<std::pair<int, const void *>, int> done;
@@ -484,18 +490,20 @@ int sei_metadata_prebuild_like(sei_metadata_t *m, sei_metadata_t *like, sei_stre
         }
     }
     // creation order = the order of the template's forward pass: strided rulebooks create the levels later ones need
+    // (one count read-back per new level); then every tiled variant is begun, ONE read-back serves them all, and they
+    // are finished -- the forward and backward passes that follow find everything built and synchronise nothing
+    std::vector<TiledRequest> want;
     for (const Item &it : items) {
         sei_rulebook_t *rb = nullptr;
         int32_t spo[3];
         if (it.subm) SEI_TRY(sei_subm_rulebook(m, it.sp, it.size, stream, &rb));
         else SEI_TRY(sei_conv_rulebook(m, it.sp, it.size, it.stride, stream, &rb, spo));
-        const TiledRules *t;
         for (int v = 0; v < SEI_NVARIANT; v++) {
-            if (it.fwd[v]) SEI_TRY(get_tiled(rb, false, 64 * (v + 1), &t, (hipStream_t)stream));
-            if (it.bwd[v]) SEI_TRY(get_tiled(rb, true, 64 * (v + 1), &t, (hipStream_t)stream));
+            if (it.fwd[v]) want.push_back(TiledRequest{rb, false, 64 * (v + 1)});
+            if (it.bwd[v] && !it.subm) want.push_back(TiledRequest{rb, true, 64 * (v + 1)});
         }
     }
-    return 0;
+    return build_tiled_batch(want, (hipStream_t)stream);
 }
 
 int sei_rulebook_info(const sei_rulebook_t *rb_c, int64_t info[8]) {
@@ -829,6 +837,12 @@ int sei_prof_query(int32_t kind, double out[4]) {
     std::lock_guard<std::mutex> lk(g_prof.mu);
     drain_locked();
     out[0] = g_prof.launches[kind]; out[1] = g_prof.ms[kind]; out[2] = g_prof.flops[kind]; out[3] = g_prof.bytes[kind];
+    return 0;
+}
+
+int sei_debug_sync_count(int64_t *count, int32_t reset) {
+    if (count) *count = (int64_t)g_sync_count.load();
+    if (reset) g_sync_count.store(0);
     return 0;
 }
 

@@ -62,6 +62,9 @@ inline int pool_alloc_t(T **out, size_t count, hipStream_t st) {
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (device, kernel); thread-safe (autograd calls in from a
 // second thread)
 int ensure_max_lds(const void *kernel, int bytes);
+// every host <-> device synchronisation the library performs goes through here and is counted
+// (sei_debug_sync_count: tests assert how many a training step needs)
+hipError_t sync_stream(hipStream_t st);
 
 // ---------------------------------------------------------------- hashing (device + host identical)
 constexpr uint64_t EMPTY_KEY = 0xFFFFFFFFFFFFFFFFull;
@@ -212,6 +215,13 @@ inline int variant_of(int tile_rows) { return tile_rows / 64 - 1; }
 int get_tiled(sei_rulebook *rb, bool transposed, int tile_rows, const TiledRules **out, hipStream_t st);
 // any already-built variant (the smallest tile size first), building the 128-row one if none exists
 int get_any_tiled(sei_rulebook *rb, bool transposed, const TiledRules **out, hipStream_t st);
+// builds every listed variant that does not exist yet with ONE stream synchronisation for all of them
+struct TiledRequest {
+    sei_rulebook *rb;
+    bool transposed;
+    int tile_rows;
+};
+int build_tiled_batch(const std::vector<TiledRequest> &want, hipStream_t st);
 int build_strided_level(sei_metadata *m, Level *lin, const int32_t size[3], const int32_t stride[3], sei_rulebook *rb,
                         hipStream_t st);
 int export_rules(const TiledRules &t, int64_t *start_host, int32_t *rin, int32_t *rout, hipStream_t st);

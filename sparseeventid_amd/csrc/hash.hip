@@ -208,7 +208,7 @@ int build_input_level(sei_metadata *m, const int32_t *coords, int64_t n, const i
     SEI_TRY(exclusive_scan_i32(flag, flag, n, err_total + 1, st));
     int32_t host[3];
     SEI_HIP(hipMemcpyAsync(host, err_total, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    SEI_HIP(hipStreamSynchronize(st));
+    SEI_HIP(sync_stream(st));
     if (host[0] != -1) {
         pool_free(slot_of); pool_free(flag); pool_free(err_total); pool_free(new_vals);
         SEI_FAIL("InputLayer: coordinate of input point " + std::to_string((uint32_t)host[0]) +
@@ -402,7 +402,7 @@ int larcv_compact(const float *in, int B, int P, int M, int D, int32_t *coords, 
     SEI_LAUNCH_CHECK();
     int32_t host;
     SEI_HIP(hipMemcpyAsync(&host, total, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    SEI_HIP(hipStreamSynchronize(st));
+    SEI_HIP(sync_stream(st));
     *n_out = host;
     pool_free(flag); pool_free(total);
     return 0;

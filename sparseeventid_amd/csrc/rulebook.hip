@@ -162,14 +162,59 @@ void free_tiled(TiledRules &t) {
     t = TiledRules();
 }
 
-// dst rows [n_dst] with coords dst_coords probe the src-level hash; result in *out.  *nbr_cache: the rulebook's k-major
-// neighbour table, probed by the first variant that is built and kept for the later ones (dW cuts its own 256-row
-// variant from it) until the rulebook is destroyed.
-static int build_tiled(const int32_t *dst_coords, int64_t n_dst, int64_t n_src, const HashTable &src_ht, int K,
-                       ProbeGeom g, int tile_rows, TiledRules *out, int32_t **nbr_cache, hipStream_t st,
-                       const int32_t *donor_nbr = nullptr, const int32_t *donor_size = nullptr) {
-    if (K > 4096) SEI_FAIL("rulebook: filter volume too large");
+// dst rows [n_dst] with coords dst_coords probe the src-level hash.  *nbr_cache: the rulebook's k-major neighbour table,
+// probed by the first variant that is built and kept for the later ones (dW cuts its own 256-row variant from it) until the
+// rulebook is destroyed.
+//
+// A tiled variant is built in two halves around ONE device -> host read-back (the sub-chunk total sizes the rule arrays):
+//   begin:  probe (if the table does not exist yet), count pass, k-major transpose, scan, totals -> pinned host memory
+//   finish: (after the stream has been synchronised) allocate the rule arrays, fill pass.
+// get_tiled() runs both with a synchronise of its own in between; sei_metadata_prebuild_like() begins EVERY variant a
+// template lists, synchronises once, and finishes them all -- one read-back per batch instead of one per variant.
+struct PendingTiled {
     TiledRules t;
+    TiledRules *dest = nullptr;
+    const int32_t *nbr = nullptr;
+    NbrView vw{};
+    int32_t *tile_subs = nullptr;
+    unsigned long long *totals = nullptr;   // device: [2] = sub-chunk total (scan), [4..] = striped rule counts
+    unsigned long long *host = nullptr;     // pinned: the same words after the read-back
+    bool empty = false;
+};
+
+constexpr int TOTAL_WORDS = 4 + RULE_STRIPES;
+
+// pinned staging for the read-backs: blocks of TOTAL_WORDS words, recycled
+namespace {
+std::mutex g_stage_mu;
+std::vector<unsigned long long *> g_stage_free;
+}  // namespace
+static unsigned long long *stage_get() {
+    std::lock_guard<std::mutex> lk(g_stage_mu);
+    if (!g_stage_free.empty()) {
+        unsigned long long *p = g_stage_free.back();
+        g_stage_free.pop_back();
+        return p;
+    }
+    void *p = nullptr;
+    if (hipHostMalloc(&p, TOTAL_WORDS * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return (unsigned long long *)p;
+}
+static void stage_put(unsigned long long *p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(g_stage_mu);
+    g_stage_free.push_back(p);
+}
+
+static int build_tiled_begin(const int32_t *dst_coords, int64_t n_dst, int64_t n_src, const HashTable &src_ht, int K,
+                             ProbeGeom g, int tile_rows, PendingTiled *pd, int32_t **nbr_cache, hipStream_t st,
+                             const int32_t *donor_nbr = nullptr, const int32_t *donor_size = nullptr) {
+    if (K > 4096) SEI_FAIL("rulebook: filter volume too large");
+    TiledRules &t = pd->t;
+    t = TiledRules();
     t.n_dst = n_dst; t.n_src = n_src; t.K = K; t.tile_rows = tile_rows;
     t.n_tiles = (int)((n_dst + tile_rows - 1) / tile_rows);
     int nt1 = t.n_tiles > 0 ? t.n_tiles : 1;
@@ -180,16 +225,16 @@ static int build_tiled(const int32_t *dst_coords, int64_t n_dst, int64_t n_src, 
         SEI_HIP(hipMemsetAsync(t.tile_sub_start, 0, 2 * sizeof(int32_t), st));
         SEI_TRY(pool_alloc_t(&t.sub_src, 16, st)); SEI_TRY(pool_alloc_t(&t.sub_dst, 16, st));
         t.built = true;
-        *out = t;
+        pd->empty = true;
         return 0;
     }
     double bytes = 12.0 * n_dst + 8.0 * K * n_dst;
     ProfScope ps(PROF_RULES, st, 0.0, bytes);
-    int32_t *tile_subs;
-    unsigned long long *totals;
-    SEI_TRY(pool_alloc_t(&tile_subs, t.n_tiles + 1, st));
-    SEI_TRY(pool_alloc_t(&totals, 4 + RULE_STRIPES, st));  // [2] = sub-chunk total (scan), [4..] = striped rule counts
-    SEI_HIP(hipMemsetAsync(totals, 0, (4 + RULE_STRIPES) * sizeof(unsigned long long), st));
+    SEI_TRY(pool_alloc_t(&pd->tile_subs, t.n_tiles + 1, st));
+    SEI_TRY(pool_alloc_t(&pd->totals, TOTAL_WORDS, st));
+    pd->host = stage_get();
+    if (!pd->host) SEI_FAIL("rulebook: cannot allocate pinned staging memory");
+    SEI_HIP(hipMemsetAsync(pd->totals, 0, TOTAL_WORDS * sizeof(unsigned long long), st));
     NbrView vw{g.f0, g.f1, g.f2, g.f0, g.f1, g.f2};
     if (!*nbr_cache && donor_nbr) {
         // the offsets of this filter are a sub-set of the donor's table (same level, larger centred odd filter)
@@ -209,30 +254,74 @@ static int build_tiled(const int32_t *dst_coords, int64_t n_dst, int64_t n_src, 
         SEI_LAUNCH_CHECK();
         *nbr_cache = nbr;
     }
-    const int32_t *nbr = *nbr_cache ? *nbr_cache : donor_nbr;
-    tile_rules_kernel<false><<<t.n_tiles, tile_rows, K * sizeof(int), st>>>(nbr, vw, n_dst, K, tile_rows, t.n_tiles, tile_subs,
-                                                                            t.tile_seg, t.seg_start, totals, nullptr, nullptr,
+    pd->nbr = *nbr_cache ? *nbr_cache : donor_nbr;
+    pd->vw = vw;
+    tile_rules_kernel<false><<<t.n_tiles, tile_rows, K * sizeof(int), st>>>(pd->nbr, vw, n_dst, K, tile_rows, t.n_tiles, pd->tile_subs,
+                                                                            t.tile_seg, t.seg_start, pd->totals, nullptr, nullptr,
                                                                             nullptr);
     transpose_seg_kernel<<<dim3((t.n_tiles + 31) / 32, (K + 1 + 31) / 32), 256, 0, st>>>(t.tile_seg, t.seg_start, t.n_tiles, K + 1);
     SEI_LAUNCH_CHECK();
-    SEI_TRY(exclusive_scan_i32(tile_subs, t.tile_sub_start, t.n_tiles, (int32_t *)(totals + 2), st));
-    SEI_HIP(hipMemcpyAsync(t.tile_sub_start + t.n_tiles, totals + 2, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
-    unsigned long long host[4 + RULE_STRIPES];
-    SEI_HIP(hipMemcpyAsync(host, totals, (4 + RULE_STRIPES) * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-    SEI_HIP(hipStreamSynchronize(st));
-    t.n_rules = 0;
-    for (int i = 0; i < RULE_STRIPES; i++) t.n_rules += (int64_t)host[4 + i];
-    t.n_sub = (int64_t)(uint32_t)host[2];
-    int64_t ns = t.n_sub > 0 ? t.n_sub : 1;
-    SEI_TRY(pool_alloc_t(&t.sub_src, (ns + 1) * SUB_SLOTS, st));  // +1: the kernels' clamped index prefetch may touch the sub-chunk after the last
-    SEI_TRY(pool_alloc_t(&t.sub_dst, (ns + 1) * SUB_SLOTS, st));
-    tile_rules_kernel<true><<<t.n_tiles, tile_rows, 0, st>>>(nbr, vw, n_dst, K, tile_rows, t.n_tiles, nullptr, t.tile_seg, nullptr,
-                                                             nullptr, t.tile_sub_start, t.sub_src, t.sub_dst);
-    SEI_LAUNCH_CHECK();
-    pool_free(tile_subs); pool_free(totals);
-    t.built = true;
-    *out = t;
+    SEI_TRY(exclusive_scan_i32(pd->tile_subs, t.tile_sub_start, t.n_tiles, (int32_t *)(pd->totals + 2), st));
+    SEI_HIP(hipMemcpyAsync(t.tile_sub_start + t.n_tiles, pd->totals + 2, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    SEI_HIP(hipMemcpyAsync(pd->host, pd->totals, TOTAL_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     return 0;
+}
+
+// after the stream has been synchronised past build_tiled_begin's read-back
+static int build_tiled_finish(PendingTiled *pd, hipStream_t st) {
+    TiledRules &t = pd->t;
+    if (!pd->empty) {
+        const unsigned long long *host = pd->host;
+        t.n_rules = 0;
+        for (int i = 0; i < RULE_STRIPES; i++) t.n_rules += (int64_t)host[4 + i];
+        t.n_sub = (int64_t)(uint32_t)host[2];
+        int64_t ns = t.n_sub > 0 ? t.n_sub : 1;
+        SEI_TRY(pool_alloc_t(&t.sub_src, (ns + 1) * SUB_SLOTS, st));  // +1: the kernels' clamped index prefetch may touch the sub-chunk after the last
+        SEI_TRY(pool_alloc_t(&t.sub_dst, (ns + 1) * SUB_SLOTS, st));
+        ProfScope ps(PROF_RULES, st, 0.0, 8.0 * t.n_rules);
+        tile_rules_kernel<true><<<t.n_tiles, t.tile_rows, 0, st>>>(pd->nbr, pd->vw, t.n_dst, t.K, t.tile_rows, t.n_tiles, nullptr,
+                                                                   t.tile_seg, nullptr, nullptr, t.tile_sub_start, t.sub_src,
+                                                                   t.sub_dst);
+        SEI_LAUNCH_CHECK();
+        pool_free(pd->tile_subs); pool_free(pd->totals);
+        stage_put(pd->host);
+        pd->tile_subs = nullptr; pd->totals = nullptr; pd->host = nullptr;
+        t.built = true;
+    }
+    *pd->dest = t;
+    return 0;
+}
+
+static void pending_abort(PendingTiled *pd) {
+    free_tiled(pd->t);
+    pool_free(pd->tile_subs); pool_free(pd->totals);
+    stage_put(pd->host);
+}
+
+// begins one variant of a rulebook (rb->mu held by the caller); nothing to do if it is built already
+static int tiled_begin_locked(sei_rulebook *rb, bool transposed, int tile_rows, PendingTiled *pd, bool *needed, hipStream_t st) {
+    if (rb->submanifold) transposed = false;
+    TiledRules &t = (transposed ? rb->bwd : rb->fwd)[variant_of(tile_rows)];
+    *needed = !t.built;
+    if (t.built) return 0;
+    pd->dest = &t;
+    int K = rb->size[0] * rb->size[1] * rb->size[2];
+    ProbeGeom g{rb->submanifold ? 0 : 1, rb->size[0], rb->size[1], rb->size[2], rb->stride[0], rb->stride[1],
+                rb->stride[2], rb->lin->spatial[0], rb->lin->spatial[1], rb->lin->spatial[2]};
+    if (!transposed) {
+        // dst = output sites probing the input-level hash
+        const int32_t *dn = nullptr, *ds = nullptr;
+        if (rb->submanifold && !rb->nbr_fwd && rb->donor) {
+            std::lock_guard<std::mutex> ld(rb->donor->mu);
+            dn = rb->donor->nbr_fwd;  // stays valid: rulebooks of one metadata are destroyed together
+            ds = rb->donor->size;
+        }
+        return build_tiled_begin(rb->lout->coords, rb->lout->n, rb->lin->n, rb->lin->ht, K, g, tile_rows, pd, &rb->nbr_fwd, st, dn, ds);
+    }
+    // dst = input sites probing the output-level hash
+    g.mode = 2;
+    g.s0 = rb->lout->spatial[0]; g.s1 = rb->lout->spatial[1]; g.s2 = rb->lout->spatial[2];
+    return build_tiled_begin(rb->lin->coords, rb->lin->n, rb->lout->n, rb->lout->ht, K, g, tile_rows, pd, &rb->nbr_bwd, st);
 }
 
 int get_tiled(sei_rulebook *rb, bool transposed, int tile_rows, const TiledRules **out, hipStream_t st) {
@@ -241,28 +330,49 @@ int get_tiled(sei_rulebook *rb, bool transposed, int tile_rows, const TiledRules
     if (rb->submanifold) transposed = false;
     TiledRules &t = (transposed ? rb->bwd : rb->fwd)[variant_of(tile_rows)];
     if (!t.built) {
-        int K = rb->size[0] * rb->size[1] * rb->size[2];
-        ProbeGeom g{rb->submanifold ? 0 : 1, rb->size[0], rb->size[1], rb->size[2], rb->stride[0], rb->stride[1],
-                    rb->stride[2], rb->lin->spatial[0], rb->lin->spatial[1], rb->lin->spatial[2]};
-        if (!transposed) {
-            // dst = output sites probing the input-level hash
-            const int32_t *dn = nullptr, *ds = nullptr;
-            if (rb->submanifold && !rb->nbr_fwd && rb->donor) {
-                std::lock_guard<std::mutex> ld(rb->donor->mu);
-                dn = rb->donor->nbr_fwd;  // stays valid: rulebooks of one metadata are destroyed together
-                ds = rb->donor->size;
-            }
-            SEI_TRY(build_tiled(rb->lout->coords, rb->lout->n, rb->lin->n, rb->lin->ht, K, g, tile_rows, &t, &rb->nbr_fwd, st, dn,
-                                ds));
-        } else {
-            // dst = input sites probing the output-level hash
-            g.mode = 2;
-            g.s0 = rb->lout->spatial[0]; g.s1 = rb->lout->spatial[1]; g.s2 = rb->lout->spatial[2];
-            SEI_TRY(build_tiled(rb->lin->coords, rb->lin->n, rb->lout->n, rb->lout->ht, K, g, tile_rows, &t, &rb->nbr_bwd, st));
+        PendingTiled pd;
+        bool needed = false;
+        int rc = tiled_begin_locked(rb, transposed, tile_rows, &pd, &needed, st);
+        if (!rc && !pd.empty && sync_stream(st) != hipSuccess) {
+            set_error("rulebook: hipStreamSynchronize failed");
+            rc = 1;
+        }
+        if (!rc) rc = build_tiled_finish(&pd, st);
+        if (rc) {
+            pending_abort(&pd);
+            return rc;
         }
     }
     *out = &t;
     return 0;
+}
+
+// Every variant in `want` (rulebook, transposed, tile_rows) that is not built yet: begun back to back, ONE stream
+// synchronisation, then finished.  (sei_metadata_prebuild_like)
+int build_tiled_batch(const std::vector<TiledRequest> &want, hipStream_t st) {
+    std::vector<PendingTiled> pend(want.size());
+    std::vector<char> live(want.size(), 0);
+    int rc = 0;
+    bool any = false;
+    for (size_t i = 0; i < want.size() && !rc; i++) {
+        std::lock_guard<std::mutex> lk(want[i].rb->mu);
+        bool needed = false;
+        rc = tiled_begin_locked(want[i].rb, want[i].transposed, want[i].tile_rows, &pend[i], &needed, st);
+        live[i] = needed ? 1 : 0;
+        any = any || (needed && !pend[i].empty);
+        if (rc && needed) { pending_abort(&pend[i]); live[i] = 0; }
+    }
+    if (!rc && any && sync_stream(st) != hipSuccess) {
+        set_error("rulebook: hipStreamSynchronize failed");
+        rc = 1;
+    }
+    for (size_t i = 0; i < want.size(); i++) {
+        if (!live[i]) continue;
+        std::lock_guard<std::mutex> lk(want[i].rb->mu);
+        if (!rc) rc = build_tiled_finish(&pend[i], st);
+        else pending_abort(&pend[i]);
+    }
+    return rc;
 }
 
 int get_any_tiled(sei_rulebook *rb, bool transposed, const TiledRules **out, hipStream_t st) {
@@ -384,7 +494,7 @@ int build_strided_level(sei_metadata *m, Level *lin, const int32_t size[3], cons
         SEI_TRY(exclusive_scan_i32(flag, flag, cand, total, st));
         int32_t host2[2];
         SEI_HIP(hipMemcpyAsync(host2, total, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-        SEI_HIP(hipStreamSynchronize(st));
+        SEI_HIP(sync_stream(st));
         if (host2[1]) SEI_FAIL("Convolution: hash table full");
         const int32_t host = host2[0];
         lo->n = host;
@@ -446,7 +556,7 @@ int export_rules(const TiledRules &t, int64_t *start_host, int32_t *rin, int32_t
                                                                           t.sub_src, per_k);
     std::vector<unsigned long long> h(t.K + 1);
     SEI_HIP(hipMemcpyAsync(h.data(), per_k, t.K * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-    SEI_HIP(hipStreamSynchronize(st));
+    SEI_HIP(sync_stream(st));
     std::vector<unsigned long long> start(t.K + 1);
     start[0] = 0;
     for (int k = 0; k < t.K; k++) start[k + 1] = start[k] + h[k];
@@ -456,7 +566,7 @@ int export_rules(const TiledRules &t, int64_t *start_host, int32_t *rin, int32_t
         export_fill_kernel<<<(t.K + 63) / 64, 64, 0, st>>>(t.tile_sub_start, t.seg_start, t.n_tiles, t.K, t.tile_rows,
                                                           t.sub_src, t.sub_dst, per_k + t.K + 1, rin, rout);
     SEI_LAUNCH_CHECK();
-    SEI_HIP(hipStreamSynchronize(st));
+    SEI_HIP(sync_stream(st));
     pool_free(per_k);
     return 0;
 }

@@ -82,6 +82,7 @@ class Trainer:
         self.lr_schedule = lr_schedule or WarmupFlatDecay()
         self.global_step = 0
         self.device = device
+        self.batch_rulebooks = True   # build a batch's rulebooks up front from the previous batch's list (one read-back)
         self._side = None        # stream of Trainer.prefetch
         self._template = None    # metadata of the last batch that went through forward(): what prefetch() rebuilds
 
@@ -160,6 +161,14 @@ class Trainer:
                 image = image.tensor
             else:
                 image = self.encoder.input_layer(image)     # Encoder.forward passes a prepared tensor through
+                if self.batch_rulebooks and self._template is not None:
+                    # every rulebook (forward AND backward variants) the previous batch needed, built now with ONE count
+                    # read-back for all of them instead of one per variant spread over the forward and backward passes
+                    try:
+                        image.metadata.prebuild_like(self._template)
+                    except RuntimeError as e:
+                        if "no level with this spatial size" not in str(e) and "smaller than filter" not in str(e):
+                            raise
             self._template = image.metadata
         if self.fused_head:
             return self.head.forward_pooled(self.encoder.forward_pooled(image))

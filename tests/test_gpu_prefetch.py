@@ -122,3 +122,36 @@ def test_two_stream_backward_is_bit_identical():
         lib().sei_set_backward_streams(0)
     assert torch.equal(base.arena.flat, over.arena.flat)
 
+
+
+def _sync_count(reset=False):
+    import ctypes
+    from sparseeventid_amd._lib import lib
+    n = ctypes.c_int64()
+    assert lib().sei_debug_sync_count(ctypes.byref(n), 1 if reset else 0) == 0
+    return n.value
+
+
+def test_batched_rulebook_build_needs_one_readback_and_changes_nothing():
+    """From the second step on the Trainer builds every rulebook variant of the batch -- forward, transposed and dW's --
+    at the top of the forward pass from the previous batch's list (sei_metadata_prebuild_like on the main stream): ONE
+    count read-back for all of them, plus one for the InputLayer and one per strided level, and none in the backward
+    pass; the lazy path synchronises once per variant.  Training is bit-identical either way."""
+    lazy, batched = _trainer(), _trainer()
+    lazy.batch_rulebooks = False
+    data = _batches(lazy)
+    order = [0, 1, 2, 1, 0]
+    counts = {"lazy": [], "batched": []}
+    for name, tr in (("lazy", lazy), ("batched", batched)):
+        torch.manual_seed(31)
+        for i in order:
+            torch.cuda.synchronize()
+            _sync_count(reset=True)
+            tr.train_step(*data[i])
+            torch.cuda.synchronize()
+            counts[name].append(_sync_count())
+    assert torch.equal(lazy.arena.flat, batched.arena.flat)
+    levels = 2                                   # depth-2 encoder: two strided convolutions
+    assert counts["batched"][0] == counts["lazy"][0]              # first step: nothing to copy the list from
+    assert all(c == 1 + levels + 1 for c in counts["batched"][1:]), counts
+    assert all(c > 1 + levels + 1 for c in counts["lazy"]), counts
