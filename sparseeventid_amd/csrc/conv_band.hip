@@ -31,7 +31,10 @@ namespace sei {
 
 constexpr int BAND_ROWS = 64;            // dst rows of one compute wave = rulebook tile_rows
 constexpr int BAND_MAXS = BAND_ROWS / SUB_SLOTS;  // sub-chunks one offset can hold in a band
-constexpr int BAND_LAG = 4;              // weight slices the loader keeps in flight before it publishes the older one
+#ifndef SEI_BAND_LAG
+#define SEI_BAND_LAG 4
+#endif
+constexpr int BAND_LAG = SEI_BAND_LAG;              // weight slices the loader keeps in flight before it publishes the older one
 constexpr int BAND_SYNC_WORDS = 32;      // [0] slices landed, [8 + w] slices released by compute wave w
 constexpr int BAND_SPIN_CAP = 1 << 22;   // every poll loop is bounded: a lost hand-off raises g_band_timeouts, never hangs
 
