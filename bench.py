@@ -312,7 +312,10 @@ def main():
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                        "backward": ("dX and dW of a layer on two streams" if args.overlap_backward else "dX and dW back to back"),
                        "rulebooks": ("step i+1's InputLayer hash + rulebooks on a side stream during step i (once per step, inside the timed region)"
-                                     if (args.prefetch and args.mode == "train") else "built lazily in the forward pass")},
+                                     if (args.prefetch and args.mode == "train") else
+                                     ("every tiled variant of the batch built at the top of the forward pass from the previous "
+                                      "step's list, one count read-back for all (Trainer.batch_rulebooks); inside the timed region"
+                                      if args.mode == "train" and args.model == "dune3d" else "built lazily in the forward pass"))},
             "roofline": roof, "cpu_baseline": cpu,
         }
         if sync is not None:

@@ -1,0 +1,18 @@
+#!/bin/bash
+# The round's headline evidence on ONE box: bench line (with the CPU baseline), rocprofv3 kernel stats of the same command,
+# HBM traffic (separate --pmc passes), MFMA-busy pass.   SEI_COMMIT=<sha> bash tools/r03_profiles.sh
+export TMPDIR=/tmp SEI_GEN_WORKERS=${SEI_GEN_WORKERS:-16}
+mkdir -p gpurun_out/r03
+python3 bench.py --steps 10 --warmup 3 2> gpurun_out/r03/r03_bench.err | tail -1 > gpurun_out/r03/r03_bench.json
+echo "bench: $(python3 -c "import json;d=json.load(open('gpurun_out/r03/r03_bench.json'));print(round(d['value'],1),round(d['ms_per_step'],1),round(d['roofline']['frac'],3),d['cpu_baseline']['value'])")"
+rm -rf gpurun_out/r03/prof
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r03/prof -- python3 bench.py --steps 5 --warmup 2 --cpu-events 0 > gpurun_out/r03/prof.log 2>&1
+f=$(find gpurun_out/r03/prof -name "*kernel_stats.csv" | head -1); cp "$f" gpurun_out/r03/r03_bench_kernel_stats.csv 2>/dev/null; rm -rf gpurun_out/r03/prof
+echo "stats: $(head -4 gpurun_out/r03/r03_bench_kernel_stats.csv | cut -c1-160)"
+export SEI_GEN_WORKERS=1
+bash tools/traffic.sh > gpurun_out/r03/traffic.log 2>&1; cp gpurun_out/r03_conv_fwd_hbm_traffic.json gpurun_out/r03/ 2>/dev/null
+echo "traffic: $(python3 -c "import json;d=json.load(open('gpurun_out/r03/r03_conv_fwd_hbm_traffic.json'));print(d['traffic_bytes_per_launch'], d['launches'])")"
+rm -rf gpurun_out/r03/pmc
+timeout -k 10 500 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d gpurun_out/r03/pmc -- python3 bench.py --steps 1 --warmup 1 --cpu-events 0 --no-prof > gpurun_out/r03/pmc.log 2>&1
+python3 tools/pmc_sum.py gpurun_out/r03/pmc conv_ > gpurun_out/r03/r03_bench_mfma_busy.txt 2>&1; rm -rf gpurun_out/r03/pmc
+echo "pmc: $(wc -l < gpurun_out/r03/r03_bench_mfma_busy.txt) lines"

@@ -19,6 +19,6 @@ python3 tools/pmc_sum.py $out/pmc2 conv_tile >> $out/summary.txt
 rm -rf $out/pmc1 $out/pmc2
 unset SEI_GEN_WORKERS
 echo "== stamps (diagnostic build -DSEI_STAMPS)" >> $out/summary.txt
-make -C sparseeventid_amd/csrc -j16 EXTRA=-DSEI_STAMPS -B > $out/build_stamps.log 2>&1
+make -C sparseeventid_amd/csrc -j16 EXTRA="-DSEI_EXPERIMENTS -DSEI_STAMPS" -B > $out/build_stamps.log 2>&1
 timeout -k 10 200 python3 tools/stamps.py $lvl $c 2>&1 | grep -v amdgpu.ids >> $out/summary.txt
 cat $out/summary.txt

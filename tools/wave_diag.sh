@@ -23,12 +23,12 @@ rm -rf $out/pmc1 $out/pmc2 $out/pmc3
 rocprofv3 -L 2>/dev/null | grep -oE "\b(SQ|TA|TCP|TCC|GRBM)_[A-Za-z0-9_]+" | sort -u > gpurun_out/pmc_counters.txt
 unset SEI_GEN_WORKERS
 echo "== stamps (diagnostic build)" >> $out/summary.txt
-make -C sparseeventid_amd/csrc -j16 EXTRA=-DSEI_STAMPS -B > $out/build_stamps.log 2>&1
+make -C sparseeventid_amd/csrc -j16 EXTRA="-DSEI_EXPERIMENTS -DSEI_STAMPS" -B > $out/build_stamps.log 2>&1
 timeout -k 10 200 python3 tools/wave_stamps.py $lvl $c 2>&1 | grep -v amdgpu.ids >> $out/summary.txt
 for abl in 1 2 3 4 7 8; do
   echo "== ablation $abl (1 gathers cached, 2 weights L1-resident, 4 no RMW, 8 no MFMA)" >> $out/summary.txt
   rm -f sparseeventid_amd/csrc/conv_wave.o
-  make -C sparseeventid_amd/csrc -j16 EXTRA=-DSEI_WAVE_ABL=$abl > $out/build_abl$abl.log 2>&1
+  make -C sparseeventid_amd/csrc -j16 EXTRA="-DSEI_EXPERIMENTS -DSEI_WAVE_ABL=$abl" > $out/build_abl$abl.log 2>&1
   timeout -k 10 200 $micro 2>&1 | grep -E "fwd" >> $out/summary.txt
 done
 cat $out/summary.txt
