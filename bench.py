@@ -315,7 +315,7 @@ def main():
                                      if (args.prefetch and args.mode == "train") else
                                      ("every tiled variant of the batch built at the top of the forward pass from the previous "
                                       "step's list, one count read-back for all (Trainer.batch_rulebooks); inside the timed region"
-                                      if args.mode == "train" and args.model == "dune3d" else "built lazily in the forward pass"))},
+                                      if tr.batch_rulebooks else "built lazily in the forward pass"))},
             "roofline": roof, "cpu_baseline": cpu,
         }
         if sync is not None:

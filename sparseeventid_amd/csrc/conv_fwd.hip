@@ -495,7 +495,7 @@ static ConvPlan plan_tile(int nIn, int nOut, int K, int64_t n_dst) {
             if (tiles % ec == 0 && em >= 1 && em <= 4 && (ec == 1 || ec == 2)) {
                 p.maxs = em; p.cs = ec; p.blocks = 1; p.nw = 4;
                 p.slj = (nIn % 32 == 0) ? 2 : 1;
-                if (ew == 8 && ((ec == 1 && em == 1) || (ec == 2 && em == 2))) p.nw = 8;
+                if (ew == 8 && ((ec == 1 && (em == 1 || em == 2)) || (ec == 2 && em == 2))) p.nw = 8;
                 if (es == 1 || (es == 2 && nIn % 32 == 0)) p.slj = es;
                 if (eb >= 1 && ec == 1 && tiles % eb == 0) p.blocks = eb;
             }
@@ -549,6 +549,11 @@ static int launch_mfma(const TiledRules &t, const ConvPlan &p, const float *X, c
     if (p.nt == NT_ && p.cs == 1 && p.maxs == 1 && p.nw == 8 && p.slj == 1)        \
         return launch_mfma<NT_, 1, 1, 1, 8>(t, p, X, W, bias, Y, nIn, init, stats, st);
 #endif
+#define FWD_CASE8M2(NT_)                                                           \
+    if (p.nt == NT_ && p.cs == 1 && p.maxs == 2 && p.nw == 8) {                    \
+        if (p.slj == 2) return launch_mfma<NT_, 1, 2, 2, 8>(t, p, X, W, bias, Y, nIn, init, stats, st); \
+        return launch_mfma<NT_, 1, 1, 2, 8>(t, p, X, W, bias, Y, nIn, init, stats, st);                 \
+    }
 #define FWD_CASE8C(NT_)                                                            \
     if (p.nt == NT_ && p.cs == 2 && p.maxs == 2 && p.nw == 8 && p.slj == 2)       \
         return launch_mfma<NT_, 2, 2, 2, 8>(t, p, X, W, bias, Y, nIn, init, stats, st);
@@ -599,6 +604,7 @@ int conv_forward(const TiledRules &t, const float *X, const float *W, const floa
         FWD_BOTH_SLJ(12, 1, 1) FWD_BOTH_SLJ(13, 1, 1) FWD_BOTH_SLJ(14, 1, 1) FWD_BOTH_SLJ(15, 1, 1) FWD_BOTH_SLJ(16, 1, 1)
 #ifdef SEI_EXPERIMENTS  // alternates reachable through SEI_FWD_PLAN
         FWD_CASE8(2) FWD_CASE8(6) FWD_CASE8C(2) FWD_CASE8C(3) FWD_CASE8C(4) FWD_CASE8C(5)
+        FWD_CASE8M2(2) FWD_CASE8M2(3) FWD_CASE8M2(4) FWD_CASE8M2(5) FWD_CASE8M2(6)
         FWD_CASE(2, 1, 2, 4) FWD_CASE(4, 1, 2, 4) FWD_CASE(6, 1, 2, 4) FWD_CASE(2, 1, 1, 4) FWD_CASE(4, 1, 1, 4) FWD_CASE(6, 1, 1, 4)
         FWD_CASE(2, 1, 2, 1) FWD_CASE(4, 1, 2, 1) FWD_CASE(6, 1, 2, 1) FWD_CASE(2, 1, 2, 3) FWD_CASE(4, 1, 2, 3)
         FWD_CASE(4, 2, 2, 2) FWD_CASE(5, 2, 2, 2) FWD_CASE(6, 2, 2, 2) FWD_CASE(3, 2, 2, 2)

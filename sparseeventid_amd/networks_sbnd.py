@@ -153,7 +153,8 @@ class ResNet(nn.Module):
             for key in output_shape})
 
     def forward(self, x):
-        batch_size = x[-1]
+        # a prepared input-level tensor (Trainer builds the InputLayer itself to batch the rulebook builds) passes through
+        batch_size = x.batch_size() if isinstance(x, scn.SparseConvNetTensor) else x[-1]
         x = self.input_tensor(x)
         x = self.initial_convolution(x)
         for l in self.pre_convolutional_layers:

@@ -128,7 +128,7 @@ class Trainer:
         NOT overlap with the step that is still computing: the side stream first waits for everything queued on the main
         stream (pool blocks and input tensors are then safe to touch), and the build's read-backs block the host until
         then -- measured 368 vs 370 ms per step."""
-        if self.model == "sbnd" or isinstance(image, Prefetched) or not torch.cuda.is_available():
+        if isinstance(image, Prefetched) or not torch.cuda.is_available():
             return image
         if self._side is None:
             self._side = torch.cuda.Stream()
@@ -138,7 +138,7 @@ class Trainer:
         self._side.wait_stream(main)
         inputs = tuple(x for x in image[:2] if isinstance(x, torch.Tensor) and x.is_cuda)
         with torch.cuda.stream(self._side):
-            t = self.encoder.input_layer(image)
+            t = (self.encoder.input_tensor if self.model == "sbnd" else self.encoder.input_layer)(image)
             for x in inputs:
                 x.record_stream(self._side)   # read by the side stream's kernels: not reusable before they are done
             try:
@@ -153,23 +153,23 @@ class Trainer:
         return Prefetched(t, ev, inputs)
 
     def forward(self, image):
-        if self.model != "sbnd":
-            if isinstance(image, Prefetched):
-                main = torch.cuda.current_stream()
-                main.wait_event(image.event)
-                image.tensor.features.record_stream(main)   # allocated on the side stream, consumed here
-                image = image.tensor
-            else:
-                image = self.encoder.input_layer(image)     # Encoder.forward passes a prepared tensor through
-                if self.batch_rulebooks and self._template is not None:
-                    # every rulebook (forward AND backward variants) the previous batch needed, built now with ONE count
-                    # read-back for all of them instead of one per variant spread over the forward and backward passes
-                    try:
-                        image.metadata.prebuild_like(self._template)
-                    except RuntimeError as e:
-                        if "no level with this spatial size" not in str(e) and "smaller than filter" not in str(e):
-                            raise
-            self._template = image.metadata
+        layer = self.encoder.input_tensor if self.model == "sbnd" else self.encoder.input_layer
+        if isinstance(image, Prefetched):
+            main = torch.cuda.current_stream()
+            main.wait_event(image.event)
+            image.tensor.features.record_stream(main)   # allocated on the side stream, consumed here
+            image = image.tensor
+        else:
+            image = layer(image)     # Encoder.forward / ResNet.forward pass a prepared tensor through
+            if self.batch_rulebooks and self._template is not None and image.features.is_cuda:
+                # every rulebook (forward AND backward variants) the previous batch needed, built now with ONE count
+                # read-back for all of them instead of one per variant spread over the forward and backward passes
+                try:
+                    image.metadata.prebuild_like(self._template)
+                except RuntimeError as e:
+                    if "no level with this spatial size" not in str(e) and "smaller than filter" not in str(e):
+                        raise
+        self._template = image.metadata
         if self.fused_head:
             return self.head.forward_pooled(self.encoder.forward_pooled(image))
         return self.head(self.encoder(image))
