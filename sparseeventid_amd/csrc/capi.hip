@@ -302,6 +302,7 @@ static void free_level(Level *l, PoolFence f) {
     pool_free_fenced(l->coords, f);
     pool_free_fenced(l->ht.keys, f);
     pool_free_fenced(l->ht.vals, f);
+    pool_free_fenced(l->ht.filter, f);
     delete l;
 }
 

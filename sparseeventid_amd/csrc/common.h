@@ -95,6 +95,11 @@ __host__ __device__ inline uint64_t hash_probe(uint64_t s0, uint64_t t, uint64_t
     return (((s0 & ~7ull) + ((t >> 3) << 3)) & mask) | ((s0 + t) & 7ull);
 }
 
+// bit of `key` in a level's membership filter (struct HashTable below)
+__host__ __device__ inline uint64_t filter_bit(uint64_t key, uint64_t fmask) {
+    return ((mix64(key >> 5) << 5) | (key & 31ull)) & fmask;
+}
+
 #ifdef __HIPCC__
 // Insert key; the slot's value becomes the MIN candidate id that hit it (deterministic representative = first
 // appearance).  Returns the slot, or 0xFFFFFFFF when the table is full (callers raise the device error flag).
@@ -111,6 +116,14 @@ __device__ inline uint32_t hash_insert_min(uint64_t *keys, uint32_t *vals, uint6
     }
     return 0xFFFFFFFFu;
 }
+__device__ inline void filter_set(uint32_t *filter, uint64_t fmask, uint64_t key) {
+    const uint64_t b = filter_bit(key, fmask);
+    atomicOr(&filter[b >> 5], 1u << (b & 31));
+}
+__device__ inline bool filter_test(const uint32_t *__restrict__ filter, uint64_t fmask, uint64_t key) {
+    const uint64_t b = filter_bit(key, fmask);
+    return (filter[b >> 5] >> (b & 31)) & 1u;
+}
 __device__ inline int hash_find(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, uint64_t mask,
                                 uint64_t key) {
     const uint64_t s0 = hash_slot0(key, mask);
@@ -124,11 +137,19 @@ __device__ inline int hash_find(const uint64_t *__restrict__ keys, const uint32_
 }
 #endif
 
+// Membership filter beside the table: one bit per key at filter_bit(key) in a bitmap of 8 bits per table slot (>= 16 bits
+// per key, false-positive rate <= 6 %).  The rulebook probes test it first: 92 % of the stem's 125 probes per site are
+// misses, and a miss then costs one word of a bitmap that is 12x smaller than the table (8 MB at level 0: L2 / MALL
+// resident) instead of a 64-byte line of the 100 MB table.  The 32 keys that differ only in the low 5 bits of x2 share one
+// 32-bit word, so the lanes of a probe wave (neighbouring sites along x2) share words.
 struct HashTable {
     uint64_t *keys = nullptr;
     uint32_t *vals = nullptr;
     uint64_t mask = 0;
+    uint32_t *filter = nullptr;
+    uint64_t fmask = 0;  // bits in the filter - 1
 };
+
 
 // One resolution level: active sites of one spatial size.
 struct Level {

@@ -143,11 +143,31 @@ __global__ __launch_bounds__(64) void finalize_kernel(const double *__restrict__
 // thread = column; fixed order.  (finalize_kernel reads one column per wave: fed 50 000 rows directly it is a
 // latency-bound 8-byte-strided walk.)
 constexpr int STATS_ROWS = 512;
-__global__ __launch_bounds__(256) void stats_compress_kernel(const double *__restrict__ in, int64_t n_rows, int cols,
+constexpr int COMPRESS_THREADS = 1024;
+__global__ __launch_bounds__(COMPRESS_THREADS) void stats_compress_kernel(const double *__restrict__ in, int64_t n_rows, int cols,
                                                              double *__restrict__ out) {
+    // block b sums rows [r0, r1) of `in` per column.  The 1024 threads are cols x RL (row lanes): row lane q takes rows
+    // r0 + q, r0 + q + RL, ... (RL independent chains instead of one latency-bound one), and the RL partial sums of a
+    // column are combined in lane order -- a fixed order, bit-identical reruns.
+    __shared__ double part[COMPRESS_THREADS];
     const int64_t per = (n_rows + gridDim.x - 1) / gridDim.x;
     const int64_t r0 = (int64_t)blockIdx.x * per, r1 = r0 + per < n_rows ? r0 + per : n_rows;
-    for (int c = threadIdx.x; c < cols; c += 256) {
+    const int RL = cols <= COMPRESS_THREADS / 2 ? COMPRESS_THREADS / cols : 1;
+    if (RL > 1) {
+        const int c = threadIdx.x % cols, q = threadIdx.x / cols;
+        double s = 0.0;
+        if (q < RL)
+            for (int64_t r = r0 + q; r < r1; r += RL) s += in[r * cols + c];
+        part[threadIdx.x] = s;
+        __syncthreads();
+        if (threadIdx.x < cols) {
+            double t = part[threadIdx.x];
+            for (int j = 1; j < RL; j++) t += part[j * cols + threadIdx.x];
+            out[(size_t)blockIdx.x * cols + threadIdx.x] = t;
+        }
+        return;
+    }
+    for (int c = threadIdx.x; c < cols; c += COMPRESS_THREADS) {
         double s = 0.0;
         for (int64_t r = r0; r < r1; r++) s += in[r * cols + c];
         out[(size_t)blockIdx.x * cols + c] = s;
@@ -369,7 +389,7 @@ int bn_forward(const float *x, int64_t n, int C, const float *gamma, const float
             int rows = (int)n_parts;
             if (n_parts > 2 * STATS_ROWS) {
                 SEI_TRY(pool_alloc_t(&small, (size_t)STATS_ROWS * 2 * C, st));
-                stats_compress_kernel<<<STATS_ROWS, 256, 0, st>>>(stats, n_parts, 2 * C, small);
+                stats_compress_kernel<<<STATS_ROWS, COMPRESS_THREADS, 0, st>>>(stats, n_parts, 2 * C, small);
                 src = small;
                 rows = STATS_ROWS;
             }
@@ -436,7 +456,7 @@ int bn_backward(const float *x, const float *y, const float *dy, int64_t n, int 
         if (nb > 2 * STATS_ROWS) {  // coalesced compression first: a wave per channel walking 8192 rows is latency-bound
             double *small;
             SEI_TRY(pool_alloc_t(&small, (size_t)STATS_ROWS * C, st));
-            stats_compress_kernel<<<STATS_ROWS, 256, 0, st>>>(dxs, nb, C, small);
+            stats_compress_kernel<<<STATS_ROWS, COMPRESS_THREADS, 0, st>>>(dxs, nb, C, small);
             colsum_rows_kernel<<<C, 64, 0, st>>>(small, STATS_ROWS, C, dx_colsum);
             pool_free(small);
         } else {

@@ -98,7 +98,8 @@ int exclusive_scan_i32(const int32_t *in, int32_t *out, int64_t n, int32_t *tota
 
 // ------------------------------------------------------------------ hash insert (hash_insert_min: common.h)
 __global__ void input_insert_kernel(const int32_t *__restrict__ coords, int64_t n, int s0, int s1, int s2, int batch,
-                                    uint64_t *keys, uint32_t *vals, uint64_t mask, uint32_t *slot_of, int32_t *err) {
+                                    uint64_t *keys, uint32_t *vals, uint64_t mask, uint32_t *filter, uint64_t fmask,
+                                    uint32_t *slot_of, int32_t *err) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int4 c = reinterpret_cast<const int4 *>(coords)[i];
@@ -107,7 +108,9 @@ __global__ void input_insert_kernel(const int32_t *__restrict__ coords, int64_t 
         slot_of[i] = 0xFFFFFFFFu;
         return;
     }
-    const uint32_t s = hash_insert_min(keys, vals, mask, pack_key(c.x, c.y, c.z, c.w), (uint32_t)i);
+    const uint64_t key = pack_key(c.x, c.y, c.z, c.w);
+    const uint32_t s = hash_insert_min(keys, vals, mask, key, (uint32_t)i);
+    filter_set(filter, fmask, key);
     if (s == 0xFFFFFFFFu) atomicMin((unsigned int *)err + 2, 0u);  // table full (cannot happen at load <= 0.5)
     slot_of[i] = s;
 }
@@ -167,6 +170,10 @@ int alloc_table(HashTable *ht, int64_t n, hipStream_t st) {
     ht->mask = cap - 1;
     SEI_HIP(hipMemsetAsync(ht->keys, 0xFF, cap * sizeof(uint64_t), st));
     SEI_HIP(hipMemsetAsync(ht->vals, 0xFF, cap * sizeof(uint32_t), st));
+    const uint64_t fbits = cap * 8;  // power of two, >= 8192
+    SEI_TRY(pool_alloc_t(&ht->filter, fbits / 32, st));
+    ht->fmask = fbits - 1;
+    SEI_HIP(hipMemsetAsync(ht->filter, 0, fbits / 8, st));
     return 0;
 }
 
@@ -202,7 +209,7 @@ int build_input_level(sei_metadata *m, const int32_t *coords, int64_t n, const i
     const int T = 256;
     const int nb = (int)((n + T - 1) / T);
     input_insert_kernel<<<nb, T, 0, st>>>(coords, n, spatial[0], spatial[1], spatial[2], batch, lv->ht.keys,
-                                          lv->ht.vals, lv->ht.mask, slot_of, err_total);
+                                          lv->ht.vals, lv->ht.mask, lv->ht.filter, lv->ht.fmask, slot_of, err_total);
     flag_first_kernel<<<nb, T, 0, st>>>(slot_of, lv->ht.vals, n, flag);
     SEI_LAUNCH_CHECK();
     SEI_TRY(exclusive_scan_i32(flag, flag, n, err_total + 1, st));

@@ -18,7 +18,7 @@ namespace sei {
 // (92 % of the stem's 125 probes per site are misses).
 __global__ void probe_kernel(const int32_t *__restrict__ dst_coords, int64_t n_dst, int K, int KP, ProbeGeom g,
                              const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, uint64_t mask,
-                             int32_t *__restrict__ nbr) {
+                             const uint32_t *__restrict__ filter, uint64_t fmask, int32_t *__restrict__ nbr) {
     // workgroup b = (row chunk b / KP, offset b % KP): consecutive workgroups probe the SAME 256 sites under consecutive
     // offsets, so their hash-table lines are still warm (one offset over all sites, then the next, measured 12 % slower)
     const int k = (int)(blockIdx.x % (unsigned)KP);
@@ -41,7 +41,14 @@ __global__ void probe_kernel(const int32_t *__restrict__ dst_coords, int64_t n_d
             q0 = p0 / g.t0; q1 = p1 / g.t1; q2 = p2 / g.t2;
         }
         ok = ok && q0 >= 0 && q0 < g.s0 && q1 >= 0 && q1 < g.s1 && q2 >= 0 && q2 < g.s2;
-        if (ok) res = hash_find(keys, vals, mask, pack_key(q0, q1, q2, c.w));
+        if (ok) {
+            // membership filter first (common.h): most probes are misses and end at one bitmap word
+            const uint64_t key = pack_key(q0, q1, q2, c.w);
+#ifndef SEI_PROBE_NOFILTER
+            if (filter_test(filter, fmask, key))
+#endif
+                res = hash_find(keys, vals, mask, key);
+        }
     }
     if (KP == K) {
         nbr[(int64_t)k * n_dst + row] = res;
@@ -250,7 +257,7 @@ static int build_tiled_begin(const int32_t *dst_coords, int64_t n_dst, int64_t n
         const int64_t chunks = (n_dst + 255) / 256;
         if (chunks * KP >= (1ll << 31)) SEI_FAIL("rulebook: too many (site, offset) pairs for one launch");
         probe_kernel<<<(unsigned)(chunks * KP), 256, 0, st>>>(dst_coords, n_dst, K, KP, g, src_ht.keys, src_ht.vals,
-                                                             src_ht.mask, nbr);
+                                                             src_ht.mask, src_ht.filter, src_ht.fmask, nbr);
         SEI_LAUNCH_CHECK();
         *nbr_cache = nbr;
     }
@@ -405,7 +412,7 @@ __device__ inline bool candidate(int4 p, int j, const ProbeGeom &g, int o0, int 
 
 __global__ void out_insert_kernel(const int32_t *__restrict__ in_coords, int64_t n, int mult, int m1, int m2,
                                   ProbeGeom g, int o0, int o1, int o2, uint64_t *keys, uint32_t *vals, uint64_t mask,
-                                  uint32_t *slot_of, int32_t *err) {
+                                  uint32_t *filter, uint64_t fmask, uint32_t *slot_of, int32_t *err) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n * mult) return;
     int64_t i = t / mult;
@@ -416,7 +423,9 @@ __global__ void out_insert_kernel(const int32_t *__restrict__ in_coords, int64_t
         slot_of[t] = 0xFFFFFFFFu;
         return;
     }
-    const uint32_t s = hash_insert_min(keys, vals, mask, pack_key(q0, q1, q2, p.w), (uint32_t)t);
+    const uint64_t key = pack_key(q0, q1, q2, p.w);
+    const uint32_t s = hash_insert_min(keys, vals, mask, key, (uint32_t)t);
+    filter_set(filter, fmask, key);
     if (s == 0xFFFFFFFFu) *err = 1;  // table full (cannot happen at load <= 0.5)
     slot_of[t] = s;
 }
@@ -488,7 +497,7 @@ int build_strided_level(sei_metadata *m, Level *lin, const int32_t size[3], cons
         SEI_HIP(hipMemsetAsync(new_vals, 0xFF, (lo->ht.mask + 1) * sizeof(uint32_t), st));
         unsigned nb = (unsigned)((cand + 255) / 256);
         out_insert_kernel<<<nb, 256, 0, st>>>(lin->coords, n, mult, m1, m2, g, osz[0], osz[1], osz[2], lo->ht.keys,
-                                              lo->ht.vals, lo->ht.mask, slot_of, total + 1);
+                                              lo->ht.vals, lo->ht.mask, lo->ht.filter, lo->ht.fmask, slot_of, total + 1);
         out_flag_kernel<<<nb, 256, 0, st>>>(slot_of, lo->ht.vals, cand, flag);
         SEI_LAUNCH_CHECK();
         SEI_TRY(exclusive_scan_i32(flag, flag, cand, total, st));
