@@ -181,6 +181,14 @@ __device__ __forceinline__ DwOps<MT, NT> dw_load_ops(const DwItem &it, int q, in
     for (int m = 0; m < MT; m++) o.a[m] = ok ? 1.f + xr : 0.f;
 #pragma unroll
     for (int n = 0; n < NT; n++) o.b[n] = ok ? 2.f + yr : 0.f;
+#elif defined(SEI_DW_ABL_NOB)      // diagnostic: only the X gathers remain (1 of the 3 vector-memory instructions per step)
+    dw_load_vec<MT>(X + ci0 + (uint64_t)xr * (uint32_t)CIN, r16, ok, o.a);
+#pragma unroll
+    for (int n = 0; n < NT; n++) o.b[n] = ok ? 2.f + yr : 0.f;
+#elif defined(SEI_DW_ABL_NOA)      // diagnostic: only the dY gathers remain (2 of the 3)
+#pragma unroll
+    for (int m = 0; m < MT; m++) o.a[m] = ok ? 1.f + xr : 0.f;
+    dw_load_vec<NT>(dY + (uint64_t)yr * (uint32_t)COUT, r16, ok, o.b);
 #elif defined(SEI_DW_ABL_CACHED)   // diagnostic: every gather hits the caches
     dw_load_vec<MT>(X + ci0 + (uint64_t)(xr & 1023u) * (uint32_t)CIN, r16, ok, o.a);
     dw_load_vec<NT>(dY + (uint64_t)(yr & 1023u) * (uint32_t)COUT, r16, ok, o.b);
