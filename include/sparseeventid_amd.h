@@ -132,7 +132,11 @@ int sei_set_backward_streams(int32_t on);
  * (0 = the plan picks (default), 1 = workgroup-tile kernel, 2 = wave-private kernel, 3 = row-band kernel).  The
  * families produce bit-identical results (same per-row summation order); tests/test_gpu_kernels_agree.py asserts it. */
 int sei_debug_force_conv_kernel(int32_t kind);
-/* The row-band kernel's loader / compute waves hand weight slices over through LDS words they poll; every poll loop is
+/* Same for the dW kernel: 0 = the library's choice, 1 = register-operand kernel, 2 = LDS-operand (ring) kernel -- an
+ * experiment that measured slower and is compiled only with EXTRA=-DSEI_EXPERIMENTS (the shipped library returns an
+ * error for 2).  Both are deterministic; their fp32 summation orders differ (results agree to rounding). */
+int sei_debug_force_dw_kernel(int32_t kind);
+/* The row-band kernels' (and the LDS-operand dW kernel's) loader / compute waves hand data over through LDS words they poll; every poll loop is
  * bounded, and a loop that ran out (it never should) is counted here instead of hanging the GPU.  Synchronises the device. */
 int sei_debug_band_timeouts(int32_t *count, int32_t reset);
 

@@ -42,6 +42,7 @@ _SIGNATURES = {
     "sei_conv_backward": (ctypes.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_int32, ctypes.c_int32, vp]),
     "sei_set_backward_streams": (ctypes.c_int, [ctypes.c_int32]),
     "sei_debug_force_conv_kernel": (ctypes.c_int, [ctypes.c_int32]),
+    "sei_debug_force_dw_kernel": (ctypes.c_int, [ctypes.c_int32]),
     "sei_debug_band_timeouts": (ctypes.c_int, [c_i32p, ctypes.c_int32]),
     "sei_bn_forward": (ctypes.c_int, [vp, ctypes.c_int64, ctypes.c_int32, vp, vp, vp, vp, ctypes.c_float, ctypes.c_float,
                                       ctypes.c_int32, ctypes.c_float, vp, vp, vp, vp, vp]),

@@ -283,6 +283,7 @@ ProfScope::~ProfScope() {
 }  // namespace sei
 
 static std::atomic<int> g_force_kernel{0};
+static std::atomic<int> g_force_dw{0};
 namespace sei {
 int forced_conv_kernel() {
 #ifdef SEI_EXPERIMENTS  // the sweep tools of a kernel-experiment build may also pin the family through the environment
@@ -293,6 +294,15 @@ int forced_conv_kernel() {
     }
 #endif
     return g_force_kernel.load(std::memory_order_relaxed);
+}
+int forced_dw_kernel() {
+#ifdef SEI_EXPERIMENTS
+    if (const char *e = getenv("SEI_DW_KERNEL")) {
+        if (!strcmp(e, "reg")) return DW_KERNEL_REG;
+        if (!strcmp(e, "ring")) return DW_KERNEL_RING;
+    }
+#endif
+    return g_force_dw.load(std::memory_order_relaxed);
 }
 }  // namespace sei
 
@@ -707,6 +717,15 @@ int side_stream_for(hipStream_t st, SideStream *out) {
 
 int sei_set_backward_streams(int32_t on) {
     g_bwd_streams.store(on ? 1 : 0);
+    return 0;
+}
+
+int sei_debug_force_dw_kernel(int32_t kind) {
+    if (kind < DW_KERNEL_AUTO || kind > DW_KERNEL_RING) SEI_FAIL("sei_debug_force_dw_kernel: kind must be 0..2");
+#ifndef SEI_EXPERIMENTS
+    if (kind == DW_KERNEL_RING) SEI_FAIL("sei_debug_force_dw_kernel: the LDS-operand dW kernel exists only in experiment builds (make EXTRA=-DSEI_EXPERIMENTS)");
+#endif
+    g_force_dw.store(kind);
     return 0;
 }
 

@@ -265,6 +265,10 @@ ConvPlan plan_conv(int nIn, int nOut, int K, int64_t n_dst);
 // (bit-identity tests between the kernels, sweeps); AUTO = the plan picks
 enum { CONV_KERNEL_AUTO = 0, CONV_KERNEL_TILE = 1, CONV_KERNEL_WAVE = 2, CONV_KERNEL_BAND = 3 };
 int forced_conv_kernel();
+// sei_debug_force_dw_kernel(): dW kernel family (AUTO = the library's choice)
+enum { DW_KERNEL_AUTO = 0, DW_KERNEL_REG = 1, DW_KERNEL_RING = 2 };
+int forced_dw_kernel();
+int dw_ring_timeouts(int *out, bool reset);
 bool plan_wave(int nIn, int nOut, int K, int64_t n_dst, ConvPlan *p);
 bool plan_band(int nIn, int nOut, int K, int64_t n_dst, ConvPlan *p);
 // stats (optional, MFMA kernels only): per-(tile, part) column sums of the OUTPUT rows, [n_parts][2][nOut] doubles

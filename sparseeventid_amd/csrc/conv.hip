@@ -7,6 +7,7 @@
 //     partial slabs are summed in a fixed order (deterministic).
 #include "common.h"
 
+#include <limits.h>
 #include <stdlib.h>
 
 namespace sei {
@@ -74,12 +75,13 @@ constexpr int DW_TILES_PER_ITER = 128;             // tiles scanned per list ref
 constexpr int DW_LIST_CAP = DW_TILES_PER_ITER * 16;  // <= 16 sub-chunks per (tile, k)
 
 // builds in LDS the list of (sub-chunk, tile) pairs of offset k for tiles [tb, tb+128) in tile order
+template <int TPI = DW_TILES_PER_ITER>
 __device__ inline int dw_build_list(const int32_t *__restrict__ tile_sub_start, const int32_t *__restrict__ seg_start,
                                     int n_tiles, int k, int tb, int t_end, int *list_sub, int *list_tile, int *scan_tmp) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int t = tb + threadIdx.x;
     int cnt = 0, base = 0;
-    if (threadIdx.x < DW_TILES_PER_ITER && t < t_end) {
+    if (threadIdx.x < TPI && t < t_end) {
         int a = seg_start[(size_t)k * n_tiles + t], b = seg_start[(size_t)(k + 1) * n_tiles + t];
         cnt = b - a;
         base = tile_sub_start[t] + a;
@@ -284,6 +286,236 @@ __global__ __launch_bounds__(256) void conv_dw_mfma_kernel(
     for (int idx = threadIdx.x; idx < MT * 16 * COUT; idx += 256) out[idx] = red[idx];
 }
 
+#ifdef SEI_EXPERIMENTS
+// ------------------------------------------------------------------------------------------ dW, operands through LDS
+// The register-operand kernel above spends its waves on ISSUING gathers: three vector-memory instructions per 12 MFMAs
+// (profiles/r02_conv_dw_ablation.log: 111 TFLOP/s without them, 82-89 with), and every rule's dY row is fetched by each of
+// the CIN/32 workgroups that share a (k, split).  Here ONE workgroup computes the whole CIN x COUT block of a (k, split):
+//   * two LOADER waves gather the 16 X[src] rows and the 16 dY[dst] rows of a sub-chunk -- WHOLE rows, once -- into a ring
+//     slot in LDS with per-lane-address LDS-DMA (global_load_lds_dwordx4: no staging registers, 384-768 B row segments);
+//   * CIN/32 COMPUTE waves (wave w owns input planes 32 w .. 32 w + 31: 2 x NT accumulator tiles) read their operands with
+//     ds_read_b64 / b128 and issue MFMAs; their instruction stream holds no vector-memory instruction at all.
+// Hand-off as in conv_band.hip: "sub-chunks landed" words written by the loaders, a "sub-chunks released" word per
+// compute wave, bounded polls, no barrier inside a list (one per 128-tile list refill).  Every compute wave does the same
+// work per sub-chunk, so nobody waits for a slower sibling.  Accumulation order: sub-chunks in list (tile) order per
+// (k, split), splits summed in order by slab_reduce_kernel -- fixed, run-to-run deterministic.
+constexpr int DWR_SYNC_WORDS = 32;   // [0] X sub-chunks landed, [1] dY sub-chunks landed, [8 + w] released by compute wave w
+constexpr int DWR_LAG = 2;           // sub-chunks a loader keeps in flight before it publishes the older one
+constexpr int DWR_SPIN_CAP = 1 << 22;
+// diagnostic builds only (EXTRA=-DSEI_DWR_ABL=n): 1 nobody waits for the ring, 2 no MFMAs, 4 loaders issue no DMA; timing only
+#ifndef SEI_DWR_ABL
+#define SEI_DWR_ABL 0
+#endif
+constexpr int DWR_TILES_PER_ITER = 32;                   // tiles per list refill: a short list leaves LDS to the ring
+constexpr int DWR_LIST_CAP = DWR_TILES_PER_ITER * 16;
+__device__ int g_dw_timeouts;
+
+__device__ __forceinline__ int dwr_poll_ge(volatile int *word, int want, int lane) {
+    int v, spins = 0;
+    for (;;) {
+        v = __builtin_amdgcn_readfirstlane(*word);
+        if (v >= want) return v;
+        if (++spins > DWR_SPIN_CAP) {
+            if (lane == 0) atomicAdd(&g_dw_timeouts, 1);
+            return INT_MAX;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+// one loader wave: rows `row_of(li, slot r16)` of table T (row length CW floats) -> slot part `part_off` of the ring
+template <int CT16>  // CW / 16
+__device__ __forceinline__ void dwr_loader(const float *__restrict__ T, float *ring, int slot_floats, int part_off, int D,
+                                           volatile int *landed, volatile int *sync, volatile int *hdr, int ncw, int total,
+                                           const int *list_sub, const int *list_tile, int TR, bool is_x,
+                                           const int32_t *__restrict__ sub_src, const uint8_t *__restrict__ sub_dst, int lane) {
+    constexpr int CW = 16 * CT16, CPR = CW / 4, P = CT16;  // chunks of 16 B per row, DMA instructions per sub-chunk
+    const int r16 = lane & 15;
+    int row_p[P], ch_p[P];
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        const int id = 64 * p + lane;
+        row_p[p] = id / CPR;
+        ch_p[p] = id - row_p[p] * CPR;
+    }
+    auto load_rows = [&](int li) {  // lane r16: the table row of rule slot r16 (-1: padding); clamped index, no branch
+        const int lc = li < total ? li : total - 1;
+        const int64_t c = list_sub[lc];
+        const int sv = sub_src[c * SUB_SLOTS + r16];
+        if (is_x) return sv;
+        const int dv = sub_dst[c * SUB_SLOTS + r16];
+        return sv >= 0 ? list_tile[lc] * TR + dv : -1;
+    };
+    int known_free = D;
+    int rows = load_rows(0);
+    int slot = 0;
+    for (int li = 0; li < total; li++) {
+        if (li >= known_free && !(SEI_DWR_ABL & 1)) {
+            // nothing more can be issued: publish what has been issued as soon as it has landed, then wait for a slot
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) *landed = li;
+            asm volatile("" ::: "memory");
+            int spins = 0;
+            for (;;) {
+                int v = lane < ncw ? sync[8 + lane] : INT_MAX;
+#pragma unroll
+                for (int d = 1; d < 16; d <<= 1) v = min(v, __shfl_xor(v, d));
+                const int mn = __builtin_amdgcn_readfirstlane(v);
+                known_free = mn > INT_MAX - D ? INT_MAX : mn + D;
+                if (li < known_free) break;
+                if (++spins > DWR_SPIN_CAP) {
+                    if (lane == 0) atomicAdd(&g_dw_timeouts, 1);
+                    known_free = INT_MAX;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        const int cur = rows;
+        rows = load_rows(li + 1);  // BEFORE this sub-chunk's DMAs: vmcnt retires in order, the index load must not sit behind them
+        float *dst = ring + (size_t)slot * slot_floats + part_off;
+        const unsigned long long valid = __ballot(cur >= 0);
+        if (is_x && lane == 0) hdr[slot] = __popcll(valid & 0xFFFFull);
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            const int r = __shfl(cur, row_p[p]);
+            const float *src = T + (uint64_t)(uint32_t)(r > 0 ? r : 0) * (uint32_t)CW + 4 * ch_p[p];
+            if (SEI_DWR_ABL & 4) { asm volatile("" ::"v"(src)); continue; }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(dst + 256 * p), 16, 0, 0);
+        }
+        if (li >= DWR_LAG) {
+            // everything older than the last LAG sub-chunks (their DMAs + one index load each) has landed
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DWR_LAG * (P + 1)) : "memory");
+            if (lane == 0) *landed = li - DWR_LAG + 1;
+            asm volatile("" ::: "memory");
+        }
+        slot = slot + 1 == D ? 0 : slot + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) *landed = total;
+    asm volatile("" ::: "memory");
+}
+
+#ifndef SEI_DWR_MT
+#define SEI_DWR_MT 1
+#endif
+constexpr int DWR_MT = SEI_DWR_MT;   // 16-row accumulator tiles per compute wave (1: CIN/16 compute waves, 2: CIN/32)
+
+// waves per SIMD the register allocator must leave room for: 2 x NT accumulator tiles + two operand sets + the loaders' tables
+constexpr int dwr_occ(int nt) { return SEI_DWR_MT == 1 ? (nt <= 8 ? 4 : 3) : (nt <= 6 ? 4 : (nt <= 8 ? 3 : 2)); }
+
+template <int CT16, int NT>
+__global__ __launch_bounds__(64 * (CT16 / DWR_MT + 2), dwr_occ(NT)) void conv_dw_ring_kernel(
+    const float *__restrict__ X, const float *__restrict__ dY, const int32_t *__restrict__ tile_sub_start,
+    const int32_t *__restrict__ seg_start, const int32_t *__restrict__ sub_src, const uint8_t *__restrict__ sub_dst,
+    int n_tiles, int TR, int tiles_per_split, int S, int K, int D, float *__restrict__ slab) {
+    extern __shared__ float lds_f[];
+    __shared__ int list_sub[DWR_LIST_CAP];
+    __shared__ int list_tile[DWR_LIST_CAP];
+    __shared__ int scan_tmp[8];
+    __shared__ int sync_w[DWR_SYNC_WORDS];
+    __shared__ int hdr_w[16];
+    constexpr int CIN = 16 * CT16, COUT = 16 * NT, MT = DWR_MT, NCW = CT16 / MT;
+    constexpr int SLOT = SUB_SLOTS * (CIN + COUT);  // floats per ring slot: 16 X rows, then 16 dY rows
+    volatile int *sync = sync_w;
+    volatile int *hdr = hdr_w;
+    float *ring = lds_f;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int k = j % K, s = (j / K) * 8 + xcd;
+    if (s >= S) return;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r16 = lane & 15, g = lane >> 4;
+    const int ci0 = wave * MT * 16;
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; m++)
+#pragma unroll
+        for (int n = 0; n < NT; n++) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int t_begin = s * tiles_per_split;
+    const int t_end = min(n_tiles, t_begin + tiles_per_split);
+    for (int tb = t_begin; tb < t_end; tb += DWR_TILES_PER_ITER) {
+        if (threadIdx.x < DWR_SYNC_WORDS) sync[threadIdx.x] = 0;  // the ring is empty here; made visible by the list's barriers
+        if (threadIdx.x < 8 && threadIdx.x >= (blockDim.x >> 6)) scan_tmp[threadIdx.x] = 0;  // dw_build_list sums four waves' entries
+        const int total = dw_build_list<DWR_TILES_PER_ITER>(tile_sub_start, seg_start, n_tiles, k, tb, t_end, list_sub, list_tile, scan_tmp);
+        if (total > 0) {
+            if (wave == NCW) {
+                dwr_loader<CT16>(X, ring, SLOT, 0, D, &sync[0], sync, hdr, NCW, total, list_sub, list_tile, TR, true, sub_src,
+                                 sub_dst, lane);
+            } else if (wave == NCW + 1) {
+                dwr_loader<NT>(dY, ring, SLOT, SUB_SLOTS * CIN, D, &sync[1], sync, hdr, NCW, total, list_sub, list_tile, TR, false,
+                               sub_src, sub_dst, lane);
+            } else {
+                int known = 0, slot = 0;
+                for (int li = 0; li < total; li++) {
+                    if (li >= known && !(SEI_DWR_ABL & 1)) {
+                        const int a = dwr_poll_ge(&sync[0], li + 1, lane), b = dwr_poll_ge(&sync[1], li + 1, lane);
+                        known = a < b ? a : b;
+                    }
+                    const float *sx = ring + (size_t)slot * SLOT, *sy = sx + SUB_SLOTS * CIN;
+                    const int nv = __builtin_amdgcn_readfirstlane(hdr[slot]);
+                    const int steps = (nv + 3) >> 2;  // steps that hold only padding slots are skipped (wave-uniform)
+                    // operands one step ahead of the MFMAs that consume them.  The padding mask is applied AFTER the MFMAs
+                    // of the step in between (a select right at the load would wait for the LDS read there)
+                    float a_c[MT], b_c[NT];
+                    dw_load_vec<MT>(sx + g * CIN + ci0, r16, g < nv, a_c);
+                    dw_load_vec<NT>(sy + g * COUT, r16, g < nv, b_c);
+#pragma unroll 1
+                    for (int q = 0; q < steps; q++) {
+                        float a_n[MT], b_n[NT];
+                        const int rs = 4 * (q + 1) + g, rl = rs < SUB_SLOTS ? rs : SUB_SLOTS - 1;  // clamped: stays inside the slot
+                        dw_load_vec<MT>(sx + rl * CIN + ci0, r16, true, a_n);
+                        dw_load_vec<NT>(sy + rl * COUT, r16, true, b_n);
+                        __builtin_amdgcn_sched_barrier(0);  // the next step's LDS reads are issued before this step's MFMAs
+#pragma unroll
+                        for (int m = 0; m < MT; m++)
+#pragma unroll
+                            for (int n = 0; n < NT; n++) {
+                                if (SEI_DWR_ABL & 2) asm volatile("" ::"v"(a_c[m]), "v"(b_c[n]));
+                                else acc[m][n] = mfma16(a_c[m], b_c[n], acc[m][n]);
+                            }
+                        __builtin_amdgcn_sched_barrier(0);
+                        const bool okn = rs < nv;
+#pragma unroll
+                        for (int m = 0; m < MT; m++) a_c[m] = okn ? a_n[m] : 0.f;
+#pragma unroll
+                        for (int n = 0; n < NT; n++) b_c[n] = okn ? b_n[n] : 0.f;
+                    }
+                    // every LDS read of the slot has been issued before this store; a wave's LDS operations execute in order
+                    asm volatile("" ::: "memory");
+                    if (lane == 0) sync[8 + wave] = li + 1;
+                    asm volatile("" ::: "memory");
+                    slot = slot + 1 == D ? 0 : slot + 1;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // block rows ci0 .. ci0 + 31 of this wave -> slab, through the (now idle) ring for coalesced stores: D regions of
+    // 32 x COUT floats fit a ring slot pair only if CIN >= COUT; waves take turns in rounds of R regions
+    constexpr int REGION = MT * 16 * COUT;
+    const int regions = (D * SLOT) / REGION > 0 ? (D * SLOT) / REGION : 1;
+    float *out = slab + (size_t)(k * S + s) * CIN * COUT;
+    for (int w0 = 0; w0 < NCW; w0 += regions) {
+        if (wave >= w0 && wave < w0 + regions && wave < NCW) {
+            float *red = ring + (size_t)(wave - w0) * REGION;
+#pragma unroll
+            for (int m = 0; m < MT; m++)
+#pragma unroll
+                for (int n = 0; n < NT; n++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) red[dw_chan<MT>(m, 4 * g + i) * COUT + dw_chan<NT>(n, r16)] = acc[m][n][i];
+        }
+        __syncthreads();
+        const int nreg = NCW - w0 < regions ? NCW - w0 : regions;
+        for (int idx = threadIdx.x; idx < nreg * REGION; idx += blockDim.x) out[(size_t)w0 * REGION + idx] = ring[idx];
+        __syncthreads();
+    }
+}
+
+#endif  // SEI_EXPERIMENTS
+
 // dW for tiny nIn (stem: nIn = 1): HBM-bound gather of dY rows; lane = output plane, the 64/COUT lane groups
 // take different rule slots; all loads of a sub-chunk are issued together; fixed-order reductions.
 template <int CIN, int COUT>
@@ -396,6 +628,48 @@ static int launch_dw(const TiledRules &t, const float *X, const float *dY, int n
     return 0;
 }
 
+#ifdef SEI_EXPERIMENTS
+template <int CT16, int NT>
+static int launch_dw_ring(const TiledRules &t, const float *X, const float *dY, int tps, int S, int D, float *slab, hipStream_t st) {
+    constexpr int CIN = 16 * CT16, COUT = 16 * NT;
+    const size_t lds_bytes = (size_t)D * SUB_SLOTS * (CIN + COUT) * sizeof(float);
+    SEI_TRY(ensure_max_lds((const void *)conv_dw_ring_kernel<CT16, NT>, 140 * 1024));
+    dim3 grid(8 * t.K * ((S + 7) / 8), 1, 1);
+    conv_dw_ring_kernel<CT16, NT><<<grid, 64 * (CT16 / DWR_MT + 2), lds_bytes, st>>>(X, dY, t.tile_sub_start, t.seg_start, t.sub_src,
+                                                                               t.sub_dst, t.n_tiles, t.tile_rows, tps, S, t.K, D, slab);
+    SEI_LAUNCH_CHECK();
+    return 0;
+}
+
+// ring depth of the LDS-operand kernel: what fits beside the sub-chunk lists with three (two, one) workgroups per CU
+static int dw_ring_depth(int nIn, int nOut) {
+    const size_t slot = (size_t)SUB_SLOTS * (nIn + nOut) * sizeof(float), fixed = 2 * DWR_LIST_CAP * sizeof(int) + 1024;
+    for (size_t budget : {(size_t)40 * 1024, (size_t)53 * 1024, (size_t)80 * 1024, (size_t)150 * 1024}) {
+        const int d = budget > fixed ? (int)((budget - fixed) / slot) : 0;
+        if (d >= DWR_LAG + 1) return d > 8 ? 8 : d;
+    }
+    return 0;
+}
+
+#define DWR_CASE(CT_, NT_) \
+    if (nIn == 16 * CT_ && nOut == 16 * NT_) return launch_dw_ring<CT_, NT_>(t, X, dY, tps, S, D, slab, st);
+
+static bool dw_ring_instantiated(int nIn, int nOut) {
+    const int ct = nIn / 16, nt = nOut / 16;
+    if (nIn % 32 || nOut % 16 || ct < 2 || ct > 12 || nt < 2 || nt > 12) return false;
+    return nt == ct || nt == ct + 2 || ct == nt + 2;  // C -> C blocks, C -> C +- 32 down-sampling convolutions
+}
+
+static int dispatch_dw_ring(const TiledRules &t, const float *X, const float *dY, int nIn, int nOut, int tps, int S, int D,
+                            float *slab, hipStream_t st) {
+    DWR_CASE(2, 2) DWR_CASE(4, 4) DWR_CASE(6, 6) DWR_CASE(8, 8) DWR_CASE(10, 10) DWR_CASE(12, 12)
+    DWR_CASE(2, 4) DWR_CASE(4, 6) DWR_CASE(6, 8) DWR_CASE(8, 10) DWR_CASE(10, 12)
+    DWR_CASE(4, 2) DWR_CASE(6, 4) DWR_CASE(8, 6) DWR_CASE(10, 8) DWR_CASE(12, 10)
+    SEI_FAIL("conv dW: no LDS-operand instantiation");
+}
+
+#endif  // SEI_EXPERIMENTS
+
 #define DW_CASE(MT_, NT_) \
     if (mt == MT_ && nt == NT_) return launch_dw<MT_, NT_>(t, X, dY, nIn, nOut, tps, S, slab, st);
 
@@ -467,7 +741,17 @@ int conv_backward_weight(const TiledRules &t, const float *X, const float *dY, f
     SEI_TRY(pool_alloc_t(&slab, (size_t)t.K * S * per, st));
     int rc = 0;
     dim3 grid(t.K, S, 1);
-    if (mfma_ok)
+#ifdef SEI_EXPERIMENTS  // the LDS-operand kernel: measured 41-67 vs 84-94 TFLOP/s, kept out of the shipped library
+    const int ring_d = mfma_ok && dw_ring_instantiated(nIn, nOut) ? dw_ring_depth(nIn, nOut) : 0;
+    const bool use_ring = ring_d > 0 && forced_dw_kernel() == DW_KERNEL_RING;
+#else
+    const bool use_ring = false;
+#endif
+    if (use_ring) {
+#ifdef SEI_EXPERIMENTS
+        rc = dispatch_dw_ring(t, X, dY, nIn, nOut, tps, S, ring_d, slab, st);
+#endif
+    } else if (mfma_ok)
         rc = dispatch_dw(mt, nt, t, X, dY, nIn, nOut, tps, S, slab, st);
     else if (small) {
 #define SM(CIN_, COUT_) conv_dw_smallcin_kernel<CIN_, COUT_><<<grid, 256, 0, st>>>(                              \
@@ -491,6 +775,22 @@ int conv_backward_weight(const TiledRules &t, const float *X, const float *dY, f
     slab_reduce_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, st>>>(slab, dW, t.K, S, per);
     SEI_LAUNCH_CHECK();
     pool_free(slab);
+    return 0;
+}
+
+int dw_ring_timeouts(int *out, bool reset) {
+#ifdef SEI_EXPERIMENTS
+    int v = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_dw_timeouts), sizeof(int)) != hipSuccess) return 1;
+    *out = v;
+    if (reset) {
+        int z = 0;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_dw_timeouts), &z, sizeof(int)) != hipSuccess) return 1;
+    }
+#else
+    (void)reset;
+    *out = 0;
+#endif
     return 0;
 }
 

@@ -712,7 +712,12 @@ extern "C" int sei_debug_band_timeouts(int32_t *out, int32_t reset) {
         sei::set_error("sei_debug_band_timeouts: hipMemcpyFromSymbol failed");
         return 1;
     }
-    if (out) *out = v;
+    int w = 0;
+    if (sei::dw_ring_timeouts(&w, reset != 0)) {
+        sei::set_error("sei_debug_band_timeouts: hipMemcpyFromSymbol failed");
+        return 1;
+    }
+    if (out) *out = v + w;
     if (reset) {
         int z = 0;
         if (hipMemcpyToSymbol(HIP_SYMBOL(sei::g_band_timeouts), &z, sizeof(int)) != hipSuccess) return 1;

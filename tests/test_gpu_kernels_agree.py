@@ -112,3 +112,42 @@ def test_band_kernel_strided_and_transposed_rules(force_conv_kernel):
     for fam in FAMILIES[1:]:
         assert torch.equal(res["tile"][0], res[fam][0]) and torch.equal(res["tile"][1], res[fam][1]), fam
     assert _timeouts() == 0
+
+
+@pytest.mark.parametrize("ci,co,filt,rows", [(32, 32, [3, 3, 3], 2500), (64, 64, [3, 3, 3], 2500), (96, 96, [3, 3, 3], 3000),
+                                             (128, 128, [3, 3, 3], 1500), (160, 160, [3, 3, 3], 900), (192, 192, [3, 3, 3], 700),
+                                             (96, 128, [3, 3, 3], 1100), (128, 96, [1, 3, 3], 1000), (64, 64, [5, 5, 1], 900)])
+def test_dw_kernel_families_agree(ci, co, filt, rows):
+    """dW through the register-operand kernel and through the LDS-operand (ring) kernel of the EXPERIMENT build (it
+    measured slower and is not in the shipped library: skipped there): both deterministic, different (fixed) fp32
+    summation orders -- equal to rounding, and each bit-identical between two runs."""
+    import sparseeventid_amd.scn as scn
+    from sparseeventid_amd._lib import lib
+    if lib().sei_debug_force_dw_kernel(2) != 0:
+        pytest.skip("library built without -DSEI_EXPERIMENTS: no LDS-operand dW kernel")
+    lib().sei_debug_force_dw_kernel(0)
+    _timeouts(reset=True)
+    sp, B = [26, 22, 24], 3
+    t = _cloud(57 + ci, B, sp, rows)
+    n = t.features.shape[0]
+    gen = torch.Generator(device="cuda").manual_seed(ci * 7 + co)
+    x = torch.randn(n, ci, device="cuda", generator=gen)
+    gy = torch.randn(n, co, device="cuda", generator=gen)
+    conv = scn.SubmanifoldConvolution(3, ci, co, filt, False).cuda()
+    res = {}
+    try:
+        for fam, kind in (("reg", 1), ("ring", 2)):
+            assert lib().sei_debug_force_dw_kernel(kind) == 0
+            runs = []
+            for _ in range(2):
+                conv.weight.grad = None
+                y = conv(scn.SparseConvNetTensor(x.clone().requires_grad_(True), t.metadata, t.spatial_size)).features
+                y.backward(gy)
+                runs.append(conv.weight.grad.clone())
+            assert torch.equal(runs[0], runs[1]), fam
+            res[fam] = runs[0]
+    finally:
+        lib().sei_debug_force_dw_kernel(0)
+    err = float((res["reg"] - res["ring"]).abs().max() / res["reg"].abs().max())
+    assert err < 1e-5, err
+    assert _timeouts() == 0

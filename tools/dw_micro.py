@@ -43,7 +43,8 @@ def main():
             for v in a.variants:
                 for kv in ("SEI_DW_MT", "SEI_DW_FIT_KB"):
                     os.environ.pop(kv, None)
-                if v != "default":
+                lib().sei_debug_force_dw_kernel({"reg": 1, "ring": 2}.get(v, 0))
+                if v not in ("default", "reg", "ring"):
                     for kv in v.split(","):
                         k_, _, val = kv.partition("=")
                         os.environ[k_] = val
