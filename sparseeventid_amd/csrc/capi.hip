@@ -442,7 +442,10 @@ int sei_subm_rulebook(sei_metadata_t *m, const int32_t spatial[3], const int32_t
     // a larger odd filter on the same level (the 5^3 stem next to the 3^3 blocks of level 0) already probes every offset
     // of this one: the tiled lists are then cut from ITS neighbour table, no second probe
     for (auto *o : m->rulebooks)
-        if (o->submanifold && o->lin == l && o->size[0] >= filter[0] && o->size[1] >= filter[1] && o->size[2] >= filter[2]) {
+        if (o->submanifold && o->lin == l && o->size[0] >= filter[0] && o->size[1] >= filter[1] && o->size[2] >= filter[2] &&
+            (o->size[0] - filter[0]) % 2 == 0 && (o->size[1] - filter[1]) % 2 == 0 && (o->size[2] - filter[2]) % 2 == 0) {
+            // both filters are odd (checked above for every submanifold rulebook), so the size differences are even and
+            // NbrView::table_k's centring by (F - f) / 2 is exact; the explicit test keeps that true if even filters ever appear
             rb->donor = o;
             break;
         }
