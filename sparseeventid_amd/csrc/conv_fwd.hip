@@ -488,6 +488,12 @@ static ConvPlan plan_tile(int nIn, int nOut, int K, int64_t n_dst) {
             // 69.1 TFLOP/s at 96 columns, 82.7 vs 82.1 at 128, 78.0 vs 76.7 at 160 (64-event batch, one device each;
             // profiles/r02_conv_units_experiment.log); 192 columns (level 5, few tiles): slower, not used.
             p.nw = 8; p.maxs = 1; p.slj = 1; p.blocks = 2;
+            if (nOut == 96 && nIn % 32 == 0) {
+                // [r3] 96 columns in ONE block with 32-plane weight slices: the same speed within noise (75.0 vs 75.3 TFLOP/s
+                // at level 2, 359.0 vs 359.3 ms per step on one box) but every src row is gathered once instead of once per
+                // column block: raw FETCH_SIZE of the kernel 939 -> 639 MB per launch (profiles/r03_conv_tile_oneblock96.txt)
+                p.slj = 2; p.blocks = 1;
+            }
         }
 #ifdef SEI_EXPERIMENTS
         int em, ec, es, eb, ew;
@@ -549,6 +555,9 @@ static int launch_mfma(const TiledRules &t, const ConvPlan &p, const float *X, c
     if (p.nt == NT_ && p.cs == 1 && p.maxs == 1 && p.nw == 8 && p.slj == 1)        \
         return launch_mfma<NT_, 1, 1, 1, 8>(t, p, X, W, bias, Y, nIn, init, stats, st);
 #endif
+#define FWD_CASE8S2(NT_)                                                           \
+    if (p.nt == NT_ && p.cs == 1 && p.maxs == 1 && p.nw == 8 && p.slj == 2)        \
+        return launch_mfma<NT_, 1, 2, 1, 8>(t, p, X, W, bias, Y, nIn, init, stats, st);
 #define FWD_CASE8M2(NT_)                                                           \
     if (p.nt == NT_ && p.cs == 1 && p.maxs == 2 && p.nw == 8) {                    \
         if (p.slj == 2) return launch_mfma<NT_, 1, 2, 2, 8>(t, p, X, W, bias, Y, nIn, init, stats, st); \
@@ -593,8 +602,8 @@ int conv_forward(const TiledRules &t, const float *X, const float *W, const floa
     if (p.kind == 2) return conv_forward_wave(t, p, X, W, bias, Y, nIn, nOut, init, stats, st);
     if (p.kind == 3) return conv_forward_band(t, p, X, W, bias, Y, nIn, nOut, init, stats, st);
     if (p.kind == 1) {
-        // eight-wave workgroups: 96 / 128 / 160 columns in two column blocks
-        FWD_CASE8(3) FWD_CASE8(4) FWD_CASE8(5)
+        // eight-wave workgroups: 96 columns in one block, 128 / 160 (and 96 behind a 16-plane input) in two column blocks
+        FWD_CASE8(3) FWD_CASE8(4) FWD_CASE8(5) FWD_CASE8S2(6)
         // default plans
         FWD_BOTH_SLJ(1, 1, 2) FWD_BOTH_SLJ(2, 1, 2) FWD_BOTH_SLJ(3, 1, 2) FWD_BOTH_SLJ(4, 1, 2) FWD_BOTH_SLJ(5, 1, 2)
         FWD_BOTH_SLJ(6, 1, 2)
