@@ -359,8 +359,12 @@ __global__ void eval_stats_kernel(const float *rmean, const float *rvar, float e
 
 static inline unsigned ew_blocks(int64_t total_vec) {
     int64_t b = (total_vec + 255) / 256;
+    // grid-stride kernels: 3 workgroups per CU (768 on the 256-CU MI355X) measured best for the streaming BatchNorm /
+    // activation passes -- whole-step BatchNorm time 29.7 ms at 8192 blocks, 29.1 at 1536, 28.2 at 1024 and at 512, 27.5 at 768
+    // (tools/bench_ab.sh, one box; profiles/r03_elementwise_grid.log): fewer, longer-lived blocks keep each CU on long
+    // contiguous runs of its streams
 #ifndef SEI_EW_BLOCKS_MAX
-#define SEI_EW_BLOCKS_MAX 8192
+#define SEI_EW_BLOCKS_MAX 768
 #endif
     return (unsigned)(b > SEI_EW_BLOCKS_MAX ? SEI_EW_BLOCKS_MAX : (b < 1 ? 1 : b));
 }
