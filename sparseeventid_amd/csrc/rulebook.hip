@@ -88,8 +88,14 @@ __global__ void tile_rules_kernel(const int32_t *__restrict__ nbr, NbrView vw, i
     };
     if (!FILL) {
         for (int k = wave; k < K; k += nw) {
+            // all chunks of the offset are loaded before the first ballot (one dependent load per iteration left this pass
+            // latency-bound at ~1.9 TB/s of neighbour-table reads)
+            int v[4];
+#pragma unroll
+            for (int ch = 0; ch < 4; ch++) v[ch] = ch < nw ? nb_at(k, ch * 64 + lane) : -1;
             int c = 0;
-            for (int ch = 0; ch < nw; ch++) c += __popcll(__ballot(nb_at(k, ch * 64 + lane) >= 0));
+#pragma unroll
+            for (int ch = 0; ch < 4; ch++) c += __popcll(__ballot(v[ch] >= 0));
             if (lane == 0) cnt_k[k] = c;
         }
         __syncthreads();
@@ -125,8 +131,13 @@ __global__ void tile_rules_kernel(const int32_t *__restrict__ nbr, NbrView vw, i
         for (int k = wave; k < K; k += nw) {
             const int64_t slot0 = (base_sub + tile_seg[(int64_t)tile * (K + 1) + k]) * SUB_SLOTS;
             int run = 0;
-            for (int ch = 0; ch < nw; ch++) {
-                const int src = nb_at(k, ch * 64 + lane);
+            int v[4];
+#pragma unroll
+            for (int ch = 0; ch < 4; ch++) v[ch] = ch < nw ? nb_at(k, ch * 64 + lane) : -1;  // loads first, then the dependent part
+#pragma unroll
+            for (int ch = 0; ch < 4; ch++) {
+                if (ch >= nw) break;
+                const int src = v[ch];
                 const bool hit = src >= 0;
                 const unsigned long long bal = __ballot(hit);
                 if (hit) {
