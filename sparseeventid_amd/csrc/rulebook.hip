@@ -16,46 +16,60 @@ namespace sei {
 // offsets plus the centre: a hit (i -> o) at offset k is also the rule (o -> i) at the mirrored offset K-1-k, so
 // it is written to both places (the table is preset to -1) -- half the hash probes, which dominate this kernel
 // (92 % of the stem's 125 probes per site are misses).
+constexpr int PROBE_GROUP = 4;  // consecutive offsets (neighbours along x2: one filter word, one table line) per thread
+
 __global__ void probe_kernel(const int32_t *__restrict__ dst_coords, int64_t n_dst, int K, int KP, ProbeGeom g,
                              const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, uint64_t mask,
                              const uint32_t *__restrict__ filter, uint64_t fmask, int32_t *__restrict__ nbr) {
-    // workgroup b = (row chunk b / KP, offset b % KP): consecutive workgroups probe the SAME 256 sites under consecutive
-    // offsets, so their hash-table lines are still warm (one offset over all sites, then the next, measured 12 % slower)
-    const int k = (int)(blockIdx.x % (unsigned)KP);
-    const int64_t row = (int64_t)(blockIdx.x / (unsigned)KP) * blockDim.x + threadIdx.x;
+    // workgroup b = (row chunk b / KG, offset group b % KG): consecutive workgroups probe the SAME 256 sites under the
+    // following offsets, so their hash-table lines are still warm (one offset over all sites, then the next, measured 12 %
+    // slower).  [r3] a thread probes PROBE_GROUP consecutive offsets of its site: the coordinates are read once per group
+    // instead of once per offset, and the group's filter tests are independent loads in flight together.
+    const int KG = (KP + PROBE_GROUP - 1) / PROBE_GROUP;
+    const int k0 = (int)(blockIdx.x % (unsigned)KG) * PROBE_GROUP;
+    const int64_t row = (int64_t)(blockIdx.x / (unsigned)KG) * blockDim.x + threadIdx.x;
     if (row >= n_dst) return;
-    int res = -1;
-    {
-        int4 c = reinterpret_cast<const int4 *>(dst_coords)[row];
+    const int4 c = reinterpret_cast<const int4 *>(dst_coords)[row];
+    uint64_t key[PROBE_GROUP];
+    bool ok[PROBE_GROUP];
+#pragma unroll
+    for (int j = 0; j < PROBE_GROUP; j++) {
+        const int k = k0 + j;
         int a = k / (g.f1 * g.f2), rem = k - a * (g.f1 * g.f2);
         int b = rem / g.f2, d = rem - b * g.f2;
         int q0, q1, q2;
-        bool ok = true;
+        bool v = k < KP;
         if (g.mode == 0) {
             q0 = c.x - g.f0 / 2 + a; q1 = c.y - g.f1 / 2 + b; q2 = c.z - g.f2 / 2 + d;
         } else if (g.mode == 1) {
             q0 = c.x * g.t0 + a; q1 = c.y * g.t1 + b; q2 = c.z * g.t2 + d;
         } else {
             int p0 = c.x - a, p1 = c.y - b, p2 = c.z - d;
-            ok = p0 >= 0 && p1 >= 0 && p2 >= 0 && (p0 % g.t0) == 0 && (p1 % g.t1) == 0 && (p2 % g.t2) == 0;
+            v = v && p0 >= 0 && p1 >= 0 && p2 >= 0 && (p0 % g.t0) == 0 && (p1 % g.t1) == 0 && (p2 % g.t2) == 0;
             q0 = p0 / g.t0; q1 = p1 / g.t1; q2 = p2 / g.t2;
         }
-        ok = ok && q0 >= 0 && q0 < g.s0 && q1 >= 0 && q1 < g.s1 && q2 >= 0 && q2 < g.s2;
-        if (ok) {
-            // membership filter first (common.h): most probes are misses and end at one bitmap word
-            const uint64_t key = pack_key(q0, q1, q2, c.w);
-#ifndef SEI_PROBE_NOFILTER
-            if (filter_test(filter, fmask, key))
-#endif
-                res = hash_find(keys, vals, mask, key);
-        }
+        v = v && q0 >= 0 && q0 < g.s0 && q1 >= 0 && q1 < g.s1 && q2 >= 0 && q2 < g.s2;
+        key[j] = pack_key(v ? q0 : 0, v ? q1 : 0, v ? q2 : 0, c.w);
+        ok[j] = v;
     }
-    if (KP == K) {
-        nbr[(int64_t)k * n_dst + row] = res;
-    } else if (res >= 0) {
-        nbr[(int64_t)k * n_dst + row] = res;
-        if (k != K - 1 - k)  // mirrored rule: dst row `res` receives from `row` through offset K-1-k
-            nbr[(int64_t)(K - 1 - k) * n_dst + res] = (int32_t)row;
+    // membership filter first (common.h): most probes are misses and end at one bitmap word; all tests of the group are
+    // issued before the first table probe
+#ifndef SEI_PROBE_NOFILTER
+#pragma unroll
+    for (int j = 0; j < PROBE_GROUP; j++) ok[j] = ok[j] && filter_test(filter, fmask, key[j]);
+#endif
+#pragma unroll
+    for (int j = 0; j < PROBE_GROUP; j++) {
+        const int k = k0 + j;
+        if (k >= KP) break;
+        const int res = ok[j] ? hash_find(keys, vals, mask, key[j]) : -1;
+        if (KP == K) {
+            nbr[(int64_t)k * n_dst + row] = res;
+        } else if (res >= 0) {
+            nbr[(int64_t)k * n_dst + row] = res;
+            if (k != K - 1 - k)  // mirrored rule: dst row `res` receives from `row` through offset K-1-k
+                nbr[(int64_t)(K - 1 - k) * n_dst + res] = (int32_t)row;
+        }
     }
 }
 
@@ -266,8 +280,9 @@ static int build_tiled_begin(const int32_t *dst_coords, int64_t n_dst, int64_t n
         const int KP = mirror ? (K + 1) / 2 : K;
         if (mirror) SEI_HIP(hipMemsetAsync(nbr, 0xFF, (size_t)tot * sizeof(int32_t), st));
         const int64_t chunks = (n_dst + 255) / 256;
-        if (chunks * KP >= (1ll << 31)) SEI_FAIL("rulebook: too many (site, offset) pairs for one launch");
-        probe_kernel<<<(unsigned)(chunks * KP), 256, 0, st>>>(dst_coords, n_dst, K, KP, g, src_ht.keys, src_ht.vals,
+        const int KG = (KP + PROBE_GROUP - 1) / PROBE_GROUP;
+        if (chunks * KG >= (1ll << 31)) SEI_FAIL("rulebook: too many (site, offset) pairs for one launch");
+        probe_kernel<<<(unsigned)(chunks * KG), 256, 0, st>>>(dst_coords, n_dst, K, KP, g, src_ht.keys, src_ht.vals,
                                                              src_ht.mask, src_ht.filter, src_ht.fmask, nbr);
         SEI_LAUNCH_CHECK();
         *nbr_cache = nbr;
