@@ -265,7 +265,11 @@ __global__ __launch_bounds__(256) void conv_dw_mfma_kernel(
     }
     // cross-wave reduction in a fixed order (deterministic): red[ci][co]
     float *red = lds_f;
+#ifdef SEI_DW_ABL_NOREDUCE  // diagnostic: only wave 0's accumulators are written (results wrong, timing only)
+    for (int w = 0; w < 1; w++) {
+#else
     for (int w = 0; w < 4; w++) {
+#endif
         if (wave == w) {
 #pragma unroll
             for (int m = 0; m < MT; m++)
