@@ -63,13 +63,9 @@ __global__ void probe_kernel(const int32_t *__restrict__ dst_coords, int64_t n_d
         const int k = k0 + j;
         if (k >= KP) break;
         const int res = ok[j] ? hash_find(keys, vals, mask, key[j]) : -1;
-        if (KP == K) {
-            nbr[(int64_t)k * n_dst + row] = res;
-        } else if (res >= 0) {
-            nbr[(int64_t)k * n_dst + row] = res;
-            if (k != K - 1 - k)  // mirrored rule: dst row `res` receives from `row` through offset K-1-k
-                nbr[(int64_t)(K - 1 - k) * n_dst + res] = (int32_t)row;
-        }
+        nbr[(int64_t)k * n_dst + row] = res;  // the probed half (and every offset without mirroring) is written whole
+        if (KP != K && res >= 0 && k != K - 1 - k)  // mirrored rule: dst row `res` receives from `row` through offset K-1-k
+            nbr[(int64_t)(K - 1 - k) * n_dst + res] = (int32_t)row;
     }
 }
 
@@ -278,7 +274,8 @@ static int build_tiled_begin(const int32_t *dst_coords, int64_t n_dst, int64_t n
         // submanifold: dst level == src level and the filter is odd in every dimension, so rules come in mirrored pairs
         const bool mirror = g.mode == 0 && (g.f0 & 1) && (g.f1 & 1) && (g.f2 & 1) && K > 1;
         const int KP = mirror ? (K + 1) / 2 : K;
-        if (mirror) SEI_HIP(hipMemsetAsync(nbr, 0xFF, (size_t)tot * sizeof(int32_t), st));
+        // only the mirrored half (offsets KP .. K-1) is filled by scattered writes and needs the -1 preset
+        if (mirror) SEI_HIP(hipMemsetAsync(nbr + (size_t)KP * n_dst, 0xFF, (size_t)(K - KP) * n_dst * sizeof(int32_t), st));
         const int64_t chunks = (n_dst + 255) / 256;
         const int KG = (KP + PROBE_GROUP - 1) / PROBE_GROUP;
         if (chunks * KG >= (1ll << 31)) SEI_FAIL("rulebook: too many (site, offset) pairs for one launch");
