@@ -52,18 +52,40 @@ class FlatArena:
         self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
         off = 0
         self._end = {}
+        self._views = []
         for p in params:
             n = p.numel()
             self._end[id(p)] = off + (n + align - 1) // align * align
             self.flat[off:off + n].copy_(p.data.reshape(-1))
             p.data = self.flat[off:off + n].view(p.shape)
             p.grad = self.grad[off:off + n].view(p.shape)
+            self._views.append(p.grad)
             off += (n + align - 1) // align * align
         self.numel = total                                  # arena length (parameters + alignment padding)
         self.n_params = sum(p.numel() for p in params)
 
     def zero_grad(self):
         self.grad.zero_()
+
+    def detach_grads(self):
+        """Before backward(): every parameter's .grad -> None, so that autograd ASSIGNS the gradient tensors the backward
+        functions return instead of launching one `grad += g` kernel per parameter (237 for the default network)."""
+        for p in self.params:
+            p.grad = None
+
+    def gather_grads(self):
+        """After backward(): the per-parameter gradient tensors -> their slots of the flat gradient arena with ONE
+        multi-tensor copy, and .grad points at the arena views again.  Parameters that received no gradient keep the
+        zeros zero_grad() left in their slot.  Equal to accumulation into a zeroed arena (g + 0 == g)."""
+        dst, src = [], []
+        for p, v in zip(self.params, self._views):
+            g = p.grad
+            if g is not None and g.data_ptr() != v.data_ptr():
+                dst.append(v)
+                src.append(g.reshape(v.shape) if g.shape != v.shape else g)
+            p.grad = v
+        if dst:
+            torch._foreach_copy_(dst, src)
 
     def offset_after(self, module):
         """Arena offset just past the parameters of `module` (they must be a leading run of the arena)."""

@@ -177,10 +177,12 @@ class Trainer:
     def train_step(self, image, labels):
         """forward + focal loss + backward + gradient all-reduce + Adam step. Returns loss tensor."""
         self.arena.zero_grad()
+        self.arena.detach_grads()  # autograd assigns the gradients; one multi-tensor copy files them into the arena
         self.buffers.broadcast()   # DDP broadcast_buffers=True: rank 0's BN running statistics before every forward
         logits = self.forward(image)
         loss = focal_loss(logits, labels)
         loss.backward()
+        self.arena.gather_grads()
         self.arena.all_reduce_mean(self.opt_start)
         for g in self.opt.param_groups:
             g["lr"] = self.lr_schedule[self.global_step]

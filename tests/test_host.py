@@ -166,3 +166,34 @@ def test_checkpoint_roundtrip_and_encoder_only_restore(tmp_path):
     with pytest.warns(UserWarning):
         b.load_checkpoint(str(tmp_path / "lit.ckpt"))
     assert b.global_step == 5
+
+
+def test_flat_arena_gathered_gradients_equal_accumulated_gradients():
+    """FlatArena.detach_grads / gather_grads (autograd assigns the gradients, one multi-tensor copy files them into the
+    flat arena) gives the arena the autograd accumulation into a zeroed arena gives -- also for a parameter that
+    receives no gradient and for one that is used twice."""
+    from sparseeventid_amd.distributed import FlatArena
+    torch.manual_seed(4)
+    lin, unused = torch.nn.Linear(5, 4), torch.nn.Linear(3, 2)
+    net = torch.nn.ModuleList([lin, unused])
+    arena = FlatArena([net])
+    x = torch.randn(7, 5)
+
+    def loss():
+        return (lin(x) ** 2).sum() + lin(x[:3]).sum()      # lin used twice, `unused` not at all
+
+    arena.zero_grad()
+    loss().backward()                                       # accumulation into the zeroed arena views
+    want = arena.grad.clone()
+    assert float(want.abs().sum()) > 0
+    arena.grad.fill_(7.0)                                   # stale content
+    arena.zero_grad()
+    arena.detach_grads()
+    assert all(p.grad is None for p in net.parameters())
+    loss().backward()
+    arena.gather_grads()
+    assert torch.equal(arena.grad, want)
+    for p in net.parameters():                              # .grad is a view of the arena again
+        assert p.grad is not None and p.grad.data_ptr() >= arena.grad.data_ptr()
+        assert p.grad.data_ptr() < arena.grad.data_ptr() + arena.grad.numel() * 4
+    assert float(unused.weight.grad.abs().sum()) == 0.0
