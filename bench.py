@@ -113,12 +113,17 @@ def main():
                     "--gpus 1: the gradient all-reduce, parameter / buffer broadcasts and the cross-rank checks then really run "
                     "through the backend at world size 1")
     ap.add_argument("--no-prof", action="store_true", help="skip HIP-event timing of the conv kernels")
-    ap.add_argument("--overlap-backward", action="store_true", help="dX and dW of a layer on two streams (sei_set_backward_streams): "
-                    "361-363 vs 366 ms per step, but concurrent kernels' individual durations stop describing the kernels, so the "
-                    "roofline block of the JSON line is only meaningful without it")
-    ap.add_argument("--prefetch", action="store_true", help="build step i+1's InputLayer hash + rulebooks on a side stream "
-                    "during step i (Trainer.prefetch) instead of lazily inside the forward pass; measured 368.1 vs 370.1 ms "
-                    "per step -- the conv kernels leave the rulebook kernels little room to overlap")
+    ap.add_argument("--overlap-backward", type=int, nargs="?", const=2, default=2, choices=[0, 1, 2],
+                    help="where dW runs (scn.set_backward_streams): 2 (default) = on the library's side stream with ONE join per "
+                    "backward pass, so that the backlog of MFMA-bound dW kernels runs beside the dX chain AND beside its "
+                    "HBM-bound BatchNorm-backward kernels (353.7 -> 342.2 ms per step); 1 = joined per layer (350.3); "
+                    "0 = dW then dX on one stream.  With 1 / 2 the dX and dW launches share the GPU, so their individual "
+                    "durations measure the sharing: the roofline block then prices the FORWARD launches of the kernel")
+    ap.add_argument("--prefetch", dest="prefetch", action="store_true", default=True,
+                    help="(default) step i+1's InputLayer hash + rulebooks are built on a side stream WHILE step i computes "
+                    "(Trainer.prefetch(after=event)): once per step, inside the timed region; 353.7 -> 349.5 ms per step")
+    ap.add_argument("--no-prefetch", dest="prefetch", action="store_false",
+                    help="rulebooks at the top of the forward pass instead (Trainer.batch_rulebooks)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -163,19 +168,24 @@ def main():
     tr.buffers.broadcast()
     image, lab = tr.stage(tr.to_scn_input(arr), labels)   # inputs resident in HBM before timing
 
-    # --prefetch (train mode): the InputLayer hash and the rulebooks of step i+1 are built on a side stream while step i
-    # computes (Trainer.prefetch) -- once per step, inside the timed region.  Default: lazily in the forward pass.
-    prefetch = args.prefetch and args.mode == "train"
-    staged = [tr.prefetch(image) if prefetch else image]
+    # default: the InputLayer hash and the rulebooks of step i+1 are built on a side stream while step i computes
+    # (Trainer.prefetch) -- once per step, inside the timed region: K timed steps consume K builds and issue K builds.
+    # --no-prefetch: at the top of the forward pass.
+    prefetch = args.prefetch
+    inputs_ready = torch.cuda.Event()
+    inputs_ready.record()
+    staged = [tr.prefetch(image, after=inputs_ready) if prefetch else image]
 
     def step():
         if args.mode == "train":
             tr.train_step(staged[0], lab)
             if prefetch:
-                staged[0] = tr.prefetch(image)
+                staged[0] = tr.prefetch(image, after=inputs_ready)
         else:
             with torch.no_grad():
-                tr.forward(image)
+                tr.forward(staged[0])
+            if prefetch:
+                staged[0] = tr.prefetch(image, after=inputs_ready)
 
     def fence():
         torch.cuda.synchronize()
@@ -184,8 +194,10 @@ def main():
         torch.cuda.synchronize()
 
     lib = _lib.lib()
-    if args.overlap_backward:
-        lib.sei_set_backward_streams(1)
+    if args.overlap_backward and args.mode == "train":
+        from sparseeventid_amd import scn
+        scn.set_backward_streams(args.overlap_backward)
+    shared = bool(args.overlap_backward) and args.mode == "train"   # dX launches share the GPU with dW launches
     for _ in range(args.warmup):
         step()
     fence()
@@ -246,13 +258,16 @@ def main():
             # same kernel); algorithmic flops = 2*R*Cin*Cout per launch, duration from HIP events.
             q = (ctypes.c_double * 4)()
             tot_ms = tot_fl = tot_n = 0.0
+            step_fl = 0.0
             kinds = {}
             for kind, name in ((0, "conv_fwd"), (1, "conv_bwd_input"), (2, "conv_bwd_weight"), (3, "rulebook_build"),
                                (4, "batchnorm"), (6, "conv_fwd_32planes"), (7, "conv_bwd_input_32planes")):
                 lib.sei_prof_query(kind, q)
                 kinds[name] = {"launches": q[0], "ms": q[1], "gflop": q[2] / 1e9, "gbyte": q[3] / 1e9}
-                if kind in (0, 1, 6, 7):
+                if kind in ((0, 6) if shared else (0, 1, 6, 7)):
                     tot_n += q[0]; tot_ms += q[1]; tot_fl += q[2]
+                if kind in (0, 1, 2, 6, 7):
+                    step_fl += q[2]
             # the 32 -> 32 plane layers (level 0) are counted in the dominant-kernel totals AND priced on their own against
             # the HBM roofline (8 flop per algorithmic byte): algorithmic bytes / HIP-event time
             c32 = {"launches": kinds["conv_fwd_32planes"]["launches"] + kinds["conv_bwd_input_32planes"]["launches"],
@@ -276,13 +291,26 @@ def main():
                     traffic = tj["traffic_bytes_per_launch"]
                     traffic_src = {"file": "profiles/" + tname, "git_blob": hashlib.sha1(b"blob %d\0" % len(raw) + raw).hexdigest(),
                                    "measured_at_commit": tj.get("commit")}
-                roof = {"bound": "mfma", "kernel": "conv_tile_mfma_kernel + conv_wave_mfma_kernel (all forward + dX launches)",
+                roof = {"bound": "mfma",
+                        "kernel": "conv_tile_mfma_kernel + conv_wave_mfma_kernel (" +
+                                  ("all FORWARD launches; the dX launches of the same kernels run beside the dW backlog of the "
+                                   "side stream by design -- their event durations measure the sharing, see whole_step"
+                                   if shared else "all forward + dX launches") + ")",
                         "achieved": ach, "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3, "traffic": traffic,
                         "traffic_source": traffic_src,
                         "traffic_note": "HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
-                                        "(tools/traffic.sh); algorithmic bytes per launch %.3g"
-                                        % ((kinds["conv_fwd"]["gbyte"] + kinds["conv_bwd_input"]["gbyte"]) * 1e9 / max(tot_n, 1)),
+                                        "(tools/traffic.sh; counter collection serialises the kernels; average over the forward "
+                                        "and dX launches, which mirror each other); algorithmic bytes per launch %.3g"
+                                        % ((kinds["conv_fwd"]["gbyte"] + kinds["conv_bwd_input"]["gbyte"]) * 1e9
+                                           / max(kinds["conv_fwd"]["launches"] + kinds["conv_bwd_input"]["launches"], 1)),
                         "launches_per_step": tot_n / args.steps, "avg_launch_ms": tot_ms / max(tot_n, 1),
+                        # every convolution flop of the step (forward + dX + dW, 2*R*Cin*Cout each) over the STEP's wall time:
+                        # a lower bound of the MFMA fraction that no overlap of kernels can flatter
+                        "whole_step": {"algorithmic_tflop": step_fl / args.steps / 1e12,
+                                       "achieved": step_fl / args.steps / 1e12 / (ms * 1e-3), "unit": "TFLOP/s",
+                                       "frac": step_fl / args.steps / 1e12 / (ms * 1e-3) / 157.3},
+                        "per_kind_note": ("kinds on different streams overlap (dW and rulebook_build run on side streams): "
+                                          "their event durations do not add up to the step" if (shared or prefetch) else None),
                         "per_kind_per_step": {k: {kk: vv / args.steps for kk, vv in v.items()} for k, v in kinds.items()}}
                 if c32["ms"] > 0:
                     roof["hbm_view_32plane_layers"] = {
@@ -310,13 +338,16 @@ def main():
                                       "fwd+bwd+Adam" if args.mode == "train" else "fwd", args.batch, args.voxels,
                                       grid[0], grid[1], grid[2], args.kind),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world,
-                       "backward": ("dX and dW of a layer on two streams" if args.overlap_backward else "dX and dW back to back"),
-                       "rulebooks": ("step i+1's InputLayer hash + rulebooks on a side stream during step i (once per step, inside the timed region)"
-                                     if (args.prefetch and args.mode == "train") else
+                       "backward": {0: "dX and dW back to back", 1: "dX and dW of a layer on two streams, joined per layer",
+                                    2: "dW on a side stream, joined once per backward pass"}[args.overlap_backward if args.mode == "train" else 0],
+                       "rulebooks": ("step i+1's InputLayer hash + rulebooks built on a side stream while step i computes (once per step, inside the timed region)"
+                                     if prefetch else
                                      ("every tiled variant of the batch built at the top of the forward pass from the previous "
                                       "step's list, one count read-back for all (Trainer.batch_rulebooks); inside the timed region"
                                       if tr.batch_rulebooks else "built lazily in the forward pass"))},
             "roofline": roof, "cpu_baseline": cpu,
+            "hbm_peak_gb": {"torch_allocator": torch.cuda.max_memory_allocated() / 1e9,
+                            "torch_reserved": torch.cuda.max_memory_reserved() / 1e9},
         }
         if sync is not None:
             out["data_parallel_checks"] = sync

@@ -126,8 +126,17 @@ int sei_conv_backward_weight(sei_rulebook_t *rb, const float *X, const float *dY
 int sei_conv_backward(sei_rulebook_t *rb, const float *X, const float *dY, const float *W, const float *dX_init,
                       float *dX, float *dW, float *dbias, int32_t nIn, int32_t nOut, sei_stream_t stream);
 
-/* process-wide switch for sei_conv_backward (0 = back to back, the default; 1 = dW on the library's side stream) */
-int sei_set_backward_streams(int32_t on);
+/* process-wide switch for sei_conv_backward: 0 = back to back (the default); 1 = dW on the library's side stream, joined
+ * before the call returns to `stream`; 2 = dW on the side stream with a DEFERRED join: the call returns with dW still
+ * queued, later calls queue behind it, and the caller makes `stream` wait for all of them with sei_backward_join()
+ * before anything reads a dW.  In mode 2 the caller keeps X, dY and dW of every call allocated until the join
+ * (sei_backward_side_stream() hands out the side stream so that a stream-ordered allocator can be told about the use:
+ * torch.Tensor.record_stream). */
+int sei_set_backward_streams(int32_t mode);
+/* the side stream sei_conv_backward pairs with `stream` on the current device (created on first use) */
+int sei_backward_side_stream(sei_stream_t stream, sei_stream_t *side);
+/* `stream` waits for everything sei_conv_backward queued on its side stream so far (no-op if nothing was) */
+int sei_backward_join(sei_stream_t stream);
 /* Test / sweep hook: pins the forward / dX kernel family for every later convolution of the process
  * (0 = the plan picks (default), 1 = workgroup-tile kernel, 2 = wave-private kernel, 3 = row-band kernel).  The
  * families produce bit-identical results (same per-row summation order); tests/test_gpu_kernels_agree.py asserts it. */

@@ -690,7 +690,11 @@ int sei_conv_backward_weight(sei_rulebook_t *rb, const float *X, const float *dY
 // library-owned side stream (one per device and caller stream) next to dX on the caller's stream (fork after everything
 // already queued on `stream`, join before returning to it), so that the tail of one kernel -- CUs idle while the last
 // workgroups finish -- is filled by the other: 361-363 vs 366 ms per step.  Both rule variants are built on the caller's
-// stream BEFORE the fork.  Default: back to back -- concurrent kernels share the GPU, so their individual durations (HIP
+// stream BEFORE the fork.  Mode 2 (deferred join) leaves the join to the caller (sei_backward_join, once per backward
+// pass): the side stream then holds a backlog of dW kernels that also fills the time the caller's stream spends in the
+// HBM-bound BatchNorm-backward kernels between two dX kernels.  The caller owns the lifetimes: X, dY and dW of every call
+// must stay allocated until the join (the python layer uses record_stream on the side stream's handle).
+// Default: back to back -- concurrent kernels share the GPU, so their individual durations (HIP
 // events, rocprof) stop describing the kernels, and the roofline accounting of bench.py is built on those durations.
 namespace {
 struct SideStream {
@@ -718,8 +722,33 @@ int side_stream_for(hipStream_t st, SideStream *out) {
 }  // namespace
 
 
-int sei_set_backward_streams(int32_t on) {
-    g_bwd_streams.store(on ? 1 : 0);
+int sei_set_backward_streams(int32_t mode) {
+    if (mode < 0 || mode > 2) SEI_FAIL("sei_set_backward_streams: mode must be 0 (back to back), 1 (join per call) or 2 (deferred join)");
+    g_bwd_streams.store(mode);
+    return 0;
+}
+
+int sei_backward_side_stream(sei_stream_t stream, sei_stream_t *side) {
+    if (!side) SEI_FAIL("sei_backward_side_stream: null output");
+    SideStream ss;
+    SEI_TRY(side_stream_for((hipStream_t)stream, &ss));
+    *side = (sei_stream_t)ss.s;
+    return 0;
+}
+
+int sei_backward_join(sei_stream_t stream) {
+    hipStream_t st = (hipStream_t)stream;
+    int dev = 0;
+    SEI_HIP(hipGetDevice(&dev));
+    SideStream ss;
+    {
+        std::lock_guard<std::mutex> lk(g_side_mu);
+        auto it = g_side.find(std::make_pair(dev, st));
+        if (it == g_side.end() || !it->second.s) return 0;   // nothing was ever forked from this stream
+        ss = it->second;
+    }
+    SEI_HIP(hipEventRecord(ss.e_done, ss.s));
+    SEI_HIP(hipStreamWaitEvent(st, ss.e_done, 0));
     return 0;
 }
 
@@ -769,8 +798,10 @@ int sei_conv_backward(sei_rulebook_t *rb, const float *X, const float *dY, const
         rc1 = conv_backward_weight(*tw, X, dY, dW, nIn, nOut, ss.s);
     }
     const int rc2 = conv_backward_input_impl(rb, dY, W, dX_init, dX, nIn, nOut, stream);
-    SEI_HIP(hipEventRecord(ss.e_done, ss.s));
-    SEI_HIP(hipStreamWaitEvent(st, ss.e_done, 0));
+    if (g_bwd_streams.load(std::memory_order_relaxed) != 2) {   // mode 2: the caller joins (sei_backward_join)
+        SEI_HIP(hipEventRecord(ss.e_done, ss.s));
+        SEI_HIP(hipStreamWaitEvent(st, ss.e_done, 0));
+    }
     return rc1 ? rc1 : rc2;
 }
 

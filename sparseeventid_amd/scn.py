@@ -29,6 +29,43 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+# ---- dW on the library's side stream (sei_set_backward_streams): 0 back to back, 1 joined per call, 2 deferred join
+_BWD_STREAMS = 0
+_SIDE = {}
+
+
+def set_backward_streams(mode):
+    """0: dW then dX on the caller's stream (default).  1: dW on the library's side stream next to dX, joined before the
+    call returns.  2: dW stays queued on the side stream; the caller joins ONCE per backward pass (``backward_join()``,
+    ``Trainer.train_step`` does) -- the backlog of dW kernels then also runs beside the HBM-bound BatchNorm-backward
+    kernels of the dX chain.  In mode 2 the operands of every dW are pinned to the side stream (``record_stream``)."""
+    global _BWD_STREAMS
+    check(lib().sei_set_backward_streams(int(mode)))
+    _BWD_STREAMS = int(mode)
+
+
+def _pin_to_side(*tensors):
+    """mode 2: X, dY and dW are still in use on the side stream when the autograd node returns and frees them."""
+    if _BWD_STREAMS != 2:
+        return
+    cur = torch.cuda.current_stream()
+    key = (cur.device.index, cur.cuda_stream)
+    ext = _SIDE.get(key)
+    if ext is None:
+        h = ctypes.c_void_p()
+        check(lib().sei_backward_side_stream(ctypes.c_void_p(cur.cuda_stream), ctypes.byref(h)))
+        ext = _SIDE[key] = torch.cuda.ExternalStream(h.value, device=cur.device)
+    for t in tensors:
+        if t is not None:
+            t.record_stream(ext)
+
+
+def backward_join():
+    """The current stream waits for every dW queued on its side stream (no-op outside mode 2 / if none was)."""
+    if _BWD_STREAMS == 2:
+        check(lib().sei_backward_join(_stream()))
+
+
 def _triple(v):
     if isinstance(v, torch.Tensor):
         v = v.tolist()
@@ -238,6 +275,8 @@ class _Conv(torch.autograd.Function):
         if dx is not None or dw is not None:   # one call: the library overlaps dX and dW (dW on its own side stream)
             check(lib().sei_conv_backward(rb.h, _ptr(features), _ptr(dout), _ptr(weight), None, _ptr(dx), _ptr(dw), _ptr(db),
                                           nIn, nOut, _stream()))
+            if dx is not None and dw is not None:
+                _pin_to_side(features, dout, dw)
         return dx, dw, db, None
 
 
@@ -326,6 +365,7 @@ class _ResidualBlock(torch.autograd.Function):
         dw2, da1 = torch.empty_like(w2), torch.empty_like(x)
         # dW and dX of a layer in one call: the library overlaps them (dW on its own side stream)
         check(L.sei_conv_backward(rb.h, _ptr(a1), _ptr(dy2), _ptr(w2), None, _ptr(da1), _ptr(dw2), None, C, C, st))
+        _pin_to_side(a1, dy2, dw2)
         del dy2
         dy1, dg1, dbe1 = torch.empty_like(x), vec(), vec()
         db1 = vec() if ctx.has_b1 else None
@@ -338,6 +378,8 @@ class _ResidualBlock(torch.autograd.Function):
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         check(L.sei_conv_backward(rb.h, _ptr(x), _ptr(dy1), _ptr(w1), _ptr(dres) if dx is not None else None, _ptr(dx),
                                   _ptr(dw1), None, C, C, st))
+        if dx is not None:
+            _pin_to_side(x, dy1, dw1)
         return (dx, None, dw1, db1, dg1, dbe1, None, None, dw2, db2, dg2, dbe2, None, None, None, None, None, None)
 
 
@@ -388,6 +430,8 @@ class _ConvBN(torch.autograd.Function):
         dw = torch.empty_like(w) if ctx.needs_input_grad[2] else None
         if dx is not None or dw is not None:   # one call: the library overlaps dX and dW (dW on its own side stream)
             check(L.sei_conv_backward(rb.h, _ptr(x), _ptr(dy), _ptr(w), None, _ptr(dx), _ptr(dw), None, nIn, nOut, st))
+            if dx is not None and dw is not None:
+                _pin_to_side(x, dy, dw)
         return dx, None, dw, db, dg, dbe, None, None, None, None, None, None, dres
 
 

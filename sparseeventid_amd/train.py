@@ -10,6 +10,7 @@ import math
 import numpy as np
 import torch
 
+from . import scn
 from .config import IMAGE_SIZE, OUTPUT_SHAPE, Config
 from .data import larcvsparse_to_scnsparse_2d, larcvsparse_to_scnsparse_3d
 from .distributed import FlatArena, FlatBuffers
@@ -120,22 +121,30 @@ class Trainer:
         lab = {k: torch.as_tensor(v).to(self.device, non_blocking=True) for k, v in labels.items()}
         return (c, f, bs), lab
 
-    def prefetch(self, image):
+    def prefetch(self, image, after=None):
         """Builds the NEXT batch's InputLayer hash and every rulebook the last forward pass used on a side stream, ahead
         of the forward pass that needs them (the reference builds them lazily inside it, resnet.py:141-161 -> SCN
         Metadata), and hands the result to the next ``train_step``.  Same kernels, same results (every kernel is
-        deterministic); only WHERE the integer work and its count read-backs run changes: off the main stream.  It does
-        NOT overlap with the step that is still computing: the side stream first waits for everything queued on the main
-        stream (pool blocks and input tensors are then safe to touch), and the build's read-backs block the host until
-        then -- measured 368 vs 370 ms per step."""
+        deterministic); only WHERE and WHEN the integer work and its count read-backs run changes.
+
+        ``after``: a ``torch.cuda.Event`` behind which the input tensors of ``image`` are complete (recorded by the
+        caller after staging them).  The side stream then waits for that event ONLY, and the build overlaps with the
+        step still computing on the main stream: hash probes and rule compaction are latency-bound integer kernels
+        that fit beside the MFMA-bound convolutions, and their count read-backs block the host on the side stream while
+        the main stream keeps draining its queue.  Device-pool blocks need no ordering from the caller: the pool
+        releases a block behind one event per stream the library has seen (capi.hip, quarantine).  ``after=None`` is the
+        conservative form -- the side stream waits for everything queued on the main stream so far, i.e. no overlap with
+        the running step (only the placement of the work changes)."""
         if isinstance(image, Prefetched) or not torch.cuda.is_available():
             return image
         if self._side is None:
-            self._side = torch.cuda.Stream()
+            import os
+            self._side = torch.cuda.Stream(priority=int(os.environ.get("SEI_SIDE_PRIO", "0")))
         main = torch.cuda.current_stream()
-        # from here on the side stream may read the input tensors and reuse device-pool blocks that older batches
-        # released: everything that used them was queued on the main stream before this point
-        self._side.wait_stream(main)
+        if after is None:
+            self._side.wait_stream(main)
+        else:
+            self._side.wait_event(after)
         inputs = tuple(x for x in image[:2] if isinstance(x, torch.Tensor) and x.is_cuda)
         with torch.cuda.stream(self._side):
             t = (self.encoder.input_tensor if self.model == "sbnd" else self.encoder.input_layer)(image)
@@ -182,6 +191,7 @@ class Trainer:
         logits = self.forward(image)
         loss = focal_loss(logits, labels)
         loss.backward()
+        scn.backward_join()        # mode 2 of scn.set_backward_streams: the dW kernels still queued on the side stream
         self.arena.gather_grads()
         self.arena.all_reduce_mean(self.opt_start)
         for g in self.opt.param_groups:

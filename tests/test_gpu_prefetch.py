@@ -72,10 +72,17 @@ def test_prebuilt_rulebooks_equal_lazy_rulebooks():
         assert list(sa) == list(sb) and torch.equal(ia, ib) and torch.equal(oa, ob)
 
 
-def test_training_with_prefetch_is_bit_identical_to_lazy_training():
+@pytest.mark.parametrize("overlapped", [False, True])
+def test_training_with_prefetch_is_bit_identical_to_lazy_training(overlapped):
+    """overlapped: the side stream waits only for the event behind which the inputs were staged, so batch j+1's hash and
+    rulebooks are built WHILE step j computes (pool blocks released by step j-1 are fenced by the library)."""
     lazy, pre = _trainer(), _trainer()
     assert torch.equal(lazy.arena.flat, pre.arena.flat)
     batches = _batches(lazy)
+    ready = None
+    if overlapped:
+        ready = torch.cuda.Event()
+        ready.record()
     order = [0, 1, 2, 0, 1]
     losses_lazy = []
     torch.manual_seed(123)   # the heads hold nn.Dropout: both runs must draw the same masks
@@ -85,12 +92,12 @@ def test_training_with_prefetch_is_bit_identical_to_lazy_training():
     from sparseeventid_amd.train import Prefetched
     losses_pre = []
     torch.manual_seed(123)
-    staged = pre.prefetch(batches[order[0]][0])
+    staged = pre.prefetch(batches[order[0]][0], after=ready)
     assert isinstance(staged, Prefetched)
     for j, i in enumerate(order):
         loss, _ = pre.train_step(staged, batches[i][1])
         if j + 1 < len(order):
-            staged = pre.prefetch(batches[order[j + 1]][0])   # while step j is still running
+            staged = pre.prefetch(batches[order[j + 1]][0], after=ready)   # while step j is still running
         losses_pre.append(float(loss))
     torch.cuda.synchronize()
     assert losses_lazy == losses_pre
@@ -99,27 +106,31 @@ def test_training_with_prefetch_is_bit_identical_to_lazy_training():
         assert torch.equal(a, b), k
 
 
-def test_two_stream_backward_is_bit_identical():
-    """sei_set_backward_streams(1): dW of every layer on the library's side stream next to dX (sei_conv_backward) -- same kernels,
-    same results; also together with the prefetch."""
+@pytest.mark.parametrize("mode", [1, 2])
+def test_two_stream_backward_is_bit_identical(mode):
+    """scn.set_backward_streams: dW of every layer on the library's side stream next to dX (sei_conv_backward), joined per
+    layer (1) or once per backward pass (2: Trainer.train_step joins; operands pinned with record_stream) -- same kernels,
+    same results; also together with the overlapped prefetch."""
+    import sparseeventid_amd.scn as scn
     base, over = _trainer(), _trainer()
     batches = _batches(base)
-    order = [0, 1, 2, 1]
+    order = [0, 1, 2, 1, 0, 2]
     torch.manual_seed(77)
     for i in order:
         base.train_step(*batches[i])
-    from sparseeventid_amd._lib import lib
-    assert lib().sei_set_backward_streams(1) == 0
+    ready = torch.cuda.Event()
+    ready.record()
+    scn.set_backward_streams(mode)
     try:
         torch.manual_seed(77)
-        staged = over.prefetch(batches[order[0]][0])
+        staged = over.prefetch(batches[order[0]][0], after=ready)
         for j, i in enumerate(order):
             over.train_step(staged, batches[i][1])
             if j + 1 < len(order):
-                staged = over.prefetch(batches[order[j + 1]][0])
+                staged = over.prefetch(batches[order[j + 1]][0], after=ready)
         torch.cuda.synchronize()
     finally:
-        lib().sei_set_backward_streams(0)
+        scn.set_backward_streams(0)
     assert torch.equal(base.arena.flat, over.arena.flat)
 
 

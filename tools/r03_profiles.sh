@@ -9,6 +9,11 @@ rm -rf gpurun_out/r03/prof
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r03/prof -- python3 bench.py --steps 5 --warmup 2 --cpu-events 0 > gpurun_out/r03/prof.log 2>&1
 f=$(find gpurun_out/r03/prof -name "*kernel_stats.csv" | head -1); cp "$f" gpurun_out/r03/r03_bench_kernel_stats.csv 2>/dev/null; rm -rf gpurun_out/r03/prof
 echo "stats: $(head -4 gpurun_out/r03/r03_bench_kernel_stats.csv | cut -c1-160)"
+# the same step with every kernel ALONE on the GPU (no side streams): the per-kernel durations that describe the kernels
+python3 bench.py --steps 10 --warmup 3 --cpu-events 0 --overlap-backward 0 --no-prefetch 2> gpurun_out/r03/r03_bench_serial.err | tail -1 > gpurun_out/r03/r03_bench_serial.json
+echo "serial: $(python3 -c "import json;d=json.load(open('gpurun_out/r03/r03_bench_serial.json'));print(round(d['value'],1),round(d['ms_per_step'],1),round(d['roofline']['frac'],3))")"
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r03/prof -- python3 bench.py --steps 5 --warmup 2 --cpu-events 0 --overlap-backward 0 --no-prefetch > gpurun_out/r03/prof_serial.log 2>&1
+f=$(find gpurun_out/r03/prof -name "*kernel_stats.csv" | head -1); cp "$f" gpurun_out/r03/r03_bench_serial_kernel_stats.csv 2>/dev/null; rm -rf gpurun_out/r03/prof
 export SEI_GEN_WORKERS=1
 bash tools/traffic.sh > gpurun_out/r03/traffic.log 2>&1; cp gpurun_out/r03_conv_fwd_hbm_traffic.json gpurun_out/r03/ 2>/dev/null
 echo "traffic: $(python3 -c "import json;d=json.load(open('gpurun_out/r03/r03_conv_fwd_hbm_traffic.json'));print(d['traffic_bytes_per_launch'], d['launches'])")"
