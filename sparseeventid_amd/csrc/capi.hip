@@ -712,6 +712,7 @@ int side_stream_for(hipStream_t st, SideStream *out) {
     std::lock_guard<std::mutex> lk(g_side_mu);
     SideStream &ss = g_side[std::make_pair(dev, st)];
     if (!ss.s) {
+        // default priority: a more urgent dW stream measured 339.0 vs 336.7 ms per step, a more urgent main stream no change
         SEI_HIP(hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking));
         SEI_HIP(hipEventCreateWithFlags(&ss.e_in, hipEventDisableTiming));
         SEI_HIP(hipEventCreateWithFlags(&ss.e_done, hipEventDisableTiming));

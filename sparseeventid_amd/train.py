@@ -138,8 +138,7 @@ class Trainer:
         if isinstance(image, Prefetched) or not torch.cuda.is_available():
             return image
         if self._side is None:
-            import os
-            self._side = torch.cuda.Stream(priority=int(os.environ.get("SEI_SIDE_PRIO", "0")))
+            self._side = torch.cuda.Stream()   # default priority (a high-priority build stream measured no different)
         main = torch.cuda.current_stream()
         if after is None:
             self._side.wait_stream(main)
