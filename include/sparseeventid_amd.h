@@ -129,12 +129,9 @@ int sei_conv_backward(sei_rulebook_t *rb, const float *X, const float *dY, const
 /* process-wide switch for sei_conv_backward: 0 = back to back (the default); 1 = dW on the library's side stream, joined
  * before the call returns to `stream`; 2 = dW on the side stream with a DEFERRED join: the call returns with dW still
  * queued, later calls queue behind it, and the caller makes `stream` wait for all of them with sei_backward_join()
- * before anything reads a dW.  In mode 2 the caller keeps X, dY and dW of every call allocated until the join
- * (sei_backward_side_stream() hands out the side stream so that a stream-ordered allocator can be told about the use:
- * torch.Tensor.record_stream). */
+ * before anything reads a dW.  In mode 2 the caller keeps X, dY and dW of every call allocated until the join; memory
+ * released after the join may be reused by work queued on `stream` behind it. */
 int sei_set_backward_streams(int32_t mode);
-/* the side stream sei_conv_backward pairs with `stream` on the current device (created on first use) */
-int sei_backward_side_stream(sei_stream_t stream, sei_stream_t *side);
 /* `stream` waits for everything sei_conv_backward queued on its side stream so far (no-op if nothing was) */
 int sei_backward_join(sei_stream_t stream);
 /* Test / sweep hook: pins the forward / dX kernel family for every later convolution of the process

@@ -693,7 +693,7 @@ int sei_conv_backward_weight(sei_rulebook_t *rb, const float *X, const float *dY
 // stream BEFORE the fork.  Mode 2 (deferred join) leaves the join to the caller (sei_backward_join, once per backward
 // pass): the side stream then holds a backlog of dW kernels that also fills the time the caller's stream spends in the
 // HBM-bound BatchNorm-backward kernels between two dX kernels.  The caller owns the lifetimes: X, dY and dW of every call
-// must stay allocated until the join (the python layer uses record_stream on the side stream's handle).
+// must stay allocated until the join (the python layer holds the tensors and drops them after it).
 // Default: back to back -- concurrent kernels share the GPU, so their individual durations (HIP
 // events, rocprof) stop describing the kernels, and the roofline accounting of bench.py is built on those durations.
 namespace {
@@ -726,14 +726,6 @@ int side_stream_for(hipStream_t st, SideStream *out) {
 int sei_set_backward_streams(int32_t mode) {
     if (mode < 0 || mode > 2) SEI_FAIL("sei_set_backward_streams: mode must be 0 (back to back), 1 (join per call) or 2 (deferred join)");
     g_bwd_streams.store(mode);
-    return 0;
-}
-
-int sei_backward_side_stream(sei_stream_t stream, sei_stream_t *side) {
-    if (!side) SEI_FAIL("sei_backward_side_stream: null output");
-    SideStream ss;
-    SEI_TRY(side_stream_for((hipStream_t)stream, &ss));
-    *side = (sei_stream_t)ss.s;
     return 0;
 }
 
