@@ -238,17 +238,37 @@ def main():
         # (Trainer.stage_larcv) -> step.  Reported beside `value`, never as `value` (inputs resident is the metric).
         pinned = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)).pin_memory()
         k2 = max(1, min(args.steps, 5))
-        img2, lab2 = tr.stage_larcv(pinned, labels)
-        tr.train_step(img2, lab2)
+        copy = torch.cuda.Stream()
+
+        def stage_next():
+            # H2D + device-side transform on a copy stream; with --prefetch the hash / rulebook build follows it on the
+            # rulebook side stream, both beside the step that is still computing
+            with torch.cuda.stream(copy):
+                img, lb = tr.stage_larcv(pinned, labels)
+                ev = torch.cuda.Event()
+                ev.record(copy)
+            return (tr.prefetch(img, after=ev) if prefetch else img), lb, ev
+
+        def staged_step(item):
+            img, lb, ev = item
+            main = torch.cuda.current_stream()
+            main.wait_event(ev)
+            for t in list(lb.values()) + ([] if prefetch else [x for x in img[:2] if isinstance(x, torch.Tensor)]):
+                t.record_stream(main)      # allocated on the copy stream, read by the step
+            tr.train_step(img, lb)
+
+        item = stage_next()
+        staged_step(item)
+        item = stage_next()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(k2):
-            img2, lab2 = tr.stage_larcv(pinned, labels)
-            tr.train_step(img2, lab2)
+            staged_step(item)
+            item = stage_next()
         torch.cuda.synchronize()
         ms2 = (time.perf_counter() - t1) / k2 * 1e3
         staging = {"ms_per_step": ms2, "events_per_s": args.batch / (ms2 * 1e-3), "steps": k2,
-                   "path": "pinned host larcv fp32 [B,1,M,4] -> H2D -> sei_larcv_to_scn on the device -> train step"}
+                   "path": "pinned host larcv fp32 [B,1,M,4] -> H2D -> sei_larcv_to_scn on the device (copy stream, one batch ahead) -> train step"}
 
     if rank == 0:
         import ctypes
