@@ -172,6 +172,10 @@ def main():
     # (Trainer.prefetch) -- once per step, inside the timed region: K timed steps consume K builds and issue K builds.
     # --no-prefetch: at the top of the forward pass.
     prefetch = args.prefetch
+    if args.one_device and world > 1 and args.overlap_backward:
+        # rehearsal only: TWO processes on one device, each with three busy queues (step, dW backlog, rulebook build),
+        # time-slice each other to a crawl (14.8 s per step against 0.70 s with either overlap alone; tools/rehearsal_ab.sh)
+        prefetch = False
     inputs_ready = torch.cuda.Event()
     inputs_ready.record()
     staged = [tr.prefetch(image, after=inputs_ready) if prefetch else image]
