@@ -728,7 +728,7 @@ int conv_backward_weight(const TiledRules &t, const float *X, const float *dY, f
 #ifdef SEI_EXPERIMENTS  // tools/dw_micro.py
         if (const char *e = getenv("SEI_DW_MT")) {
             int em = atoi(e);
-            if (em >= 1 && em <= 4 && ct % em == 0 && em * nt <= 48) mt = em;
+            if (em >= 1 && em <= 8 && ct % em == 0 && em * nt <= 64) mt = em;
         }
 #endif
     }
