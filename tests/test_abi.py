@@ -74,3 +74,13 @@ def test_shipped_library_reads_no_environment_variable():
             code = t.split("//")[0]
             if "getenv(" in code:
                 assert any(stack), "%s:%d reads the environment outside an SEI_EXPERIMENTS block" % (f, ln)
+
+
+def test_backward_stream_switch_validates_its_mode():
+    """A pure setter (no GPU call): modes 0..2 only; the join is a no-op when nothing was forked."""
+    from sparseeventid_amd import _lib
+    L = _lib.lib()
+    assert L.sei_set_backward_streams(3) != 0 and b"mode must be" in L.sei_last_error()
+    assert L.sei_set_backward_streams(-1) != 0
+    for m in (1, 2, 0):
+        assert L.sei_set_backward_streams(m) == 0
