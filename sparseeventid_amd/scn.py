@@ -32,6 +32,7 @@ def _ptr(t):
 # ---- dW on the library's side stream (sei_set_backward_streams): 0 back to back, 1 joined per call, 2 deferred join
 _BWD_STREAMS = 0
 _HELD = []
+_DW_PTRS = set()
 
 
 def set_backward_streams(mode):
@@ -47,22 +48,38 @@ def set_backward_streams(mode):
     if _HELD:
         torch.cuda.synchronize()
         _HELD.clear()
+    _DW_PTRS.clear()
     check(lib().sei_set_backward_streams(int(mode)))
     _BWD_STREAMS = int(mode)
 
 
-def _pin_to_side(*tensors):
-    """mode 2: X, dY and dW are still in use on the side stream when the autograd node returns."""
+def _pin_to_side(x, dy, dw):
+    """mode 2: X and dY are still being read on the side stream when the autograd node returns: held until the join.
+    dW is NOT held: autograd's AccumulateGrad takes over a gradient tensor as ``param.grad`` only while nobody else
+    references it, and otherwise CLONES it on the spot -- on the caller's stream, before the side stream has written it.
+    Its address is remembered instead, so that the join can verify the gradients autograd kept are the buffers the
+    kernels wrote (``backward_join(params)``)."""
     if _BWD_STREAMS == 2:
-        _HELD.append(tensors)
+        _HELD.append((x, dy))
+        _DW_PTRS.add(dw.data_ptr())
 
 
-def backward_join():
+def backward_join(params=None):
     """The current stream waits for every dW queued on its side stream; the operands held for them are released (their
-    memory is reused by work queued on this stream AFTER the wait).  No-op outside mode 2."""
+    memory is reused by work queued on this stream AFTER the wait).  ``params``: the parameters of the model -- every
+    dW buffer queued since the last join must BE the ``.grad`` of one of them (autograd took it over instead of copying
+    it before it was written), else RuntimeError.  No-op outside mode 2."""
     if _BWD_STREAMS == 2:
         check(lib().sei_backward_join(_stream()))
         _HELD.clear()
+        queued = set(_DW_PTRS)
+        _DW_PTRS.clear()
+        if params is not None and queued:
+            kept = {p.grad.data_ptr() for p in params if p.grad is not None}
+            if not queued <= kept:
+                raise RuntimeError("set_backward_streams(2): %d weight gradients were copied by autograd before their kernels "
+                                   "ran (accumulation into an existing .grad, or a hook holding the tensor): use mode 1, or "
+                                   "clear .grad before backward()" % len(queued - kept))
 
 
 

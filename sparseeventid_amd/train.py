@@ -190,7 +190,9 @@ class Trainer:
         logits = self.forward(image)
         loss = focal_loss(logits, labels)
         loss.backward()
-        scn.backward_join()        # mode 2 of scn.set_backward_streams: the dW kernels still queued on the side stream
+        # mode 2 of scn.set_backward_streams: the dW kernels still queued on the side stream (and a check that the
+        # gradients autograd kept are the buffers those kernels wrote)
+        scn.backward_join(self.arena.params)
         self.arena.gather_grads()
         self.arena.all_reduce_mean(self.opt_start)
         for g in self.opt.param_groups:

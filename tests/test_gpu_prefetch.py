@@ -135,6 +135,63 @@ def test_two_stream_backward_is_bit_identical(mode):
 
 
 
+def test_overlapped_step_is_bit_identical_at_full_size():
+    """The default network on full-size events (kernels of milliseconds: the dW side stream really lags behind the dX
+    chain, the rulebook stream really runs beside the step): six steps on changing batches, overlapped (dW joined once
+    per backward pass + rulebooks one batch ahead) against serial -- final parameters bit-identical.  (The 32^3 cases
+    above finish each kernel before the next is queued and cannot see an ordering hole; tools/soak.py found one.)"""
+    import sparseeventid_amd.scn as scn
+    from bench import generate_batch
+    from sparseeventid_amd.train import Trainer
+    data = [generate_batch(0, i, 4, (900, 900, 900), 50000 - 5000 * i, "tracks", 4) for i in range(3)]
+    runs = {}
+    for name in ("serial", "overlapped"):
+        torch.manual_seed(99)
+        tr = Trainer(image_size=[1, 900, 900, 900], device="cuda", seed=5)
+        staged = [tr.stage(tr.to_scn_input(arr), labels) for arr, labels in data]
+        order = [0, 1, 2, 1, 0, 2]
+        if name == "serial":
+            for i in order:
+                tr.train_step(*staged[i])
+        else:
+            ready = torch.cuda.Event()
+            ready.record()
+            scn.set_backward_streams(2)
+            try:
+                nxt = tr.prefetch(staged[order[0]][0], after=ready)
+                for j, i in enumerate(order):
+                    tr.train_step(nxt, staged[i][1])
+                    if j + 1 < len(order):
+                        nxt = tr.prefetch(staged[order[j + 1]][0], after=ready)
+                torch.cuda.synchronize()
+            finally:
+                scn.set_backward_streams(0)
+        torch.cuda.synchronize()
+        runs[name] = tr.arena.flat.clone()
+        del tr, staged
+    assert torch.equal(runs["serial"], runs["overlapped"])
+
+
+def test_deferred_join_detects_a_gradient_autograd_copied():
+    """Mode 2 relies on autograd TAKING OVER the dW tensor as param.grad (no kernel).  If something else holds the tensor
+    (here: a tensor hook that keeps it), AccumulateGrad clones it on the main stream before the side stream has written
+    it -- the join must refuse that instead of training on garbage."""
+    import sparseeventid_amd.scn as scn
+    tr = _trainer()
+    batches = _batches(tr)
+    kept = []
+    w = next(p for n, p in tr.encoder.named_parameters() if n.endswith("convolution_2.conv1.weight"))
+    h = w.register_hook(lambda g: kept.append(g))
+    scn.set_backward_streams(2)
+    try:
+        with pytest.raises(RuntimeError, match="copied by autograd"):
+            tr.train_step(*batches[0])
+    finally:
+        h.remove()
+        torch.cuda.synchronize()
+        scn.set_backward_streams(0)
+
+
 def _sync_count(reset=False):
     import ctypes
     from sparseeventid_amd._lib import lib
