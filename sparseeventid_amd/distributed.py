@@ -53,8 +53,10 @@ class FlatArena:
         off = 0
         self._end = {}
         self._views = []
+        self.spans = []                                     # (offset, numel) of every parameter in the arena
         for p in params:
             n = p.numel()
+            self.spans.append((off, n))
             self._end[id(p)] = off + (n + align - 1) // align * align
             self.flat[off:off + n].copy_(p.data.reshape(-1))
             p.data = self.flat[off:off + n].view(p.shape)

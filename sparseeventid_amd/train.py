@@ -215,20 +215,91 @@ class Trainer:
     # state_dict-compatible checkpoints: {"state_dict": {"encoder.*", "head.*"}, "global_step", "optimizer"}.  The
     # "state_dict" / "global_step" entries are what the reference reads back (create_trainer.py:93-115: it loads the
     # ``encoder.*`` keys of ckpt["state_dict"]); Lightning's own "optimizer_states" / "lr_schedulers" / "epoch" / "loops"
-    # entries are NOT written: "optimizer" holds the Adam state of this Trainer's ONE flat parameter, so a reference
-    # ``fit(ckpt_path=...)`` can take the weights from these files but not resume its optimizer from them, and
-    # load_checkpoint() of a real Lightning file restores weights and step only (and says so).
+    # entries are written only by save_checkpoint(lightning_layout=True) ("optimizer_states" = the flat Adam moments sliced
+    # per parameter, "lr_schedulers", "epoch"; never "callbacks" / "loops"); "optimizer" holds the Adam state of this
+    # Trainer's ONE flat parameter.  load_checkpoint() of a real Lightning file restores weights, step and -- from its
+    # per-parameter "optimizer_states" -- the moments.
     def state_dict(self):
         sd = {"encoder." + k: v for k, v in self.encoder.state_dict().items()}
         sd.update({"head." + k: v for k, v in self.head.state_dict().items()})
         return sd
 
-    def save_checkpoint(self, path):
+    def optimizer_state_per_parameter(self):
+        """The Adam state in ``torch.optim.Adam(model.parameters()).state_dict()`` layout -- parameter i of
+        [encoder.parameters() + head.parameters()] -> {"step", "exp_avg", "exp_avg_sq"} -- i.e. what a Lightning
+        checkpoint holds in ``optimizer_states[0]`` for the reference's optimizer (supervised_eventID.py:198-207):
+        slices of this Trainer's ONE flat moment pair.  Frozen parameters (before opt_start) carry no state, as
+        parameters without a gradient do in torch."""
+        own = self.opt.state_dict()
+        flat = own["state"].get(0)
+        state = {}
+        if flat is not None:
+            for i, (p, (off, n)) in enumerate(zip(self.arena.params, self.arena.spans)):
+                if off < self.opt_start:
+                    continue
+                a = off - self.opt_start
+                state[i] = {"step": flat["step"].detach().clone().cpu(),
+                            "exp_avg": flat["exp_avg"][a:a + n].detach().view(p.shape).clone().cpu(),
+                            "exp_avg_sq": flat["exp_avg_sq"][a:a + n].detach().view(p.shape).clone().cpu()}
+        group = {k: v for k, v in own["param_groups"][0].items() if k != "params"}
+        group["fused"] = None
+        group["params"] = list(range(len(self.arena.params)))
+        return {"state": state, "param_groups": [group]}
+
+    def load_optimizer_state_per_parameter(self, sd):
+        """Inverse of ``optimizer_state_per_parameter``: per-parameter Adam moments (a Lightning ``optimizer_states[0]``
+        of the reference's run, or this Trainer's own export) -> the flat moment pair.  All parameters must be at the
+        same step (they are: one optimizer, stepped together)."""
+        per = sd.get("state", {})
+        if not per:
+            import warnings
+            warnings.warn("the checkpoint's optimizer_states hold no moments: weights and global_step were restored, the "
+                          "optimizer starts from zero moments")
+            return
+        per = {int(k): v for k, v in per.items()}
+        steps = {float(torch.as_tensor(v["step"]).item()) for v in per.values()}
+        if len(steps) != 1:
+            raise ValueError("per-parameter optimizer state at different steps %s: not one Adam stepped together" % sorted(steps))
+        dev = self.flat_param.device
+        m = torch.zeros_like(self.flat_param.data)
+        v2 = torch.zeros_like(self.flat_param.data)
+        for i, (p, (off, n)) in enumerate(zip(self.arena.params, self.arena.spans)):
+            if i not in per:
+                continue
+            if off < self.opt_start:
+                raise ValueError("checkpoint holds optimizer state for parameter %d, which is frozen in this trainer" % i)
+            for name, dst in (("exp_avg", m), ("exp_avg_sq", v2)):
+                t = per[i][name]
+                if tuple(t.shape) != tuple(p.shape):
+                    raise ValueError("optimizer state %s of parameter %d has shape %s, the parameter %s"
+                                     % (name, i, tuple(t.shape), tuple(p.shape)))
+                a = off - self.opt_start
+                dst[a:a + n].copy_(t.reshape(-1).to(dev))
+        own = self.opt.state_dict()
+        own["state"] = {0: {"step": torch.tensor(steps.pop(), dtype=torch.float32), "exp_avg": m, "exp_avg_sq": v2}}
+        self.opt.load_state_dict(own)
+        self.flat_param.grad = self.arena.grad[self.opt_start:]
+
+    def save_checkpoint(self, path, lightning_layout=False):
+        """``lightning_layout=True`` adds the keys a Lightning ``fit(ckpt_path=...)`` resume reads for the reference's
+        single Adam + LambdaLR pair (create_trainer.py:83-115): ``optimizer_states`` (per-parameter moments, see
+        ``optimizer_state_per_parameter``), ``lr_schedulers`` (step counters of the LambdaLR the reference wraps its
+        schedule in) and ``epoch``.  The per-parameter optimizer state is checked against a plain ``torch.optim.Adam`` over
+        the same parameters (tests/test_host.py); Lightning itself is not installed here, so its loader was never run on
+        these files: ``callbacks`` / ``loops`` are not written."""
         import os
         os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
-        torch.save({"state_dict": {k: v.detach().cpu() for k, v in self.state_dict().items()},
-                    "global_step": self.global_step, "optimizer": self.opt.state_dict(),
-                    "opt_start": self.opt_start, "arena_numel": int(self.arena.numel)}, path)
+        ck = {"state_dict": {k: v.detach().cpu() for k, v in self.state_dict().items()},
+              "global_step": self.global_step, "optimizer": self.opt.state_dict(),
+              "opt_start": self.opt_start, "arena_numel": int(self.arena.numel)}
+        if lightning_layout:
+            step = int(self.global_step)
+            lr = float(self.lr_schedule[step])
+            ck["epoch"] = 0
+            ck["optimizer_states"] = [self.optimizer_state_per_parameter()]
+            ck["lr_schedulers"] = [{"base_lrs": [1.0], "last_epoch": step, "_step_count": step + 1, "_last_lr": [lr],
+                                    "lr_lambdas": [None]}]
+        torch.save(ck, path)
 
     def _load_into(self, module, prefix, state):
         sub = {k[len(prefix):]: v for k, v in state.items() if k.startswith(prefix)}
@@ -263,10 +334,9 @@ class Trainer:
                                              % (int(st[k].numel()), want, ck.get("opt_start", "?"), self.opt_start))
                 self.opt.load_state_dict(ck["optimizer"])
                 self.flat_param.grad = self.arena.grad[self.opt_start:]
-            elif "optimizer_states" in ck:
-                import warnings
-                warnings.warn("checkpoint carries Lightning optimizer_states (per-parameter Adam moments); only the weights "
-                              "and global_step were restored -- the optimizer starts from zero moments")
+            elif ck.get("optimizer_states"):
+                # a Lightning checkpoint of the reference's run: per-parameter Adam moments -> the flat pair
+                self.load_optimizer_state_per_parameter(ck["optimizer_states"][0])
 
     def restore_encoder_only(self, path, freeze=True):
         """mode.weights_location + restore_encoder_only (create_trainer.py:93-106): load the ``encoder.*`` keys

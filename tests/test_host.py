@@ -142,7 +142,7 @@ def test_checkpoint_roundtrip_and_encoder_only_restore(tmp_path):
     assert all(torch.equal(v, enc_before[k]) for k, v in c.encoder.state_dict().items())
     assert not torch.equal(c.head.state_dict()["classification_head.labelneutID.2.weight"], head_before)
     assert "Img/s" in format_log_message({"loss/loss": 1.25}, 64, 3, dt=0.5, mode="train")
-    # a shape-mismatched tensor is an error, not a silent broadcast; a Lightning-style file warns about its optimizer state
+    # a shape-mismatched tensor is an error, not a silent broadcast; a Lightning-style file with an EMPTY optimizer state warns
     import pytest
     bad = dict(ck)
     bad["state_dict"] = dict(ck["state_dict"])
@@ -197,3 +197,77 @@ def test_flat_arena_gathered_gradients_equal_accumulated_gradients():
         assert p.grad is not None and p.grad.data_ptr() >= arena.grad.data_ptr()
         assert p.grad.data_ptr() < arena.grad.data_ptr() + arena.grad.numel() * 4
     assert float(unused.weight.grad.abs().sum()) == 0.0
+
+
+def test_lightning_layout_optimizer_state_matches_per_parameter_adam(tmp_path):
+    """`save_checkpoint(lightning_layout=True)` writes `optimizer_states[0]` in the layout of
+    `torch.optim.Adam(model.parameters()).state_dict()` (what Lightning stores for the reference's optimizer,
+    supervised_eventID.py:198-207 / create_trainer.py:110-115): a plain per-parameter Adam that loads it takes the same
+    next step as the Trainer's flat fused-arena Adam, and a Trainer that loads a per-parameter state (a reference-run
+    checkpoint) continues exactly like the run that wrote it."""
+    from sparseeventid_amd.config import Config, Encoder
+    from sparseeventid_amd.train import Trainer
+    cfg = Config(encoder=Encoder(depth=1, n_initial_filters=16, n_output_filters=16, blocks_per_layer=1))
+    a = Trainer(cfg=cfg, image_size=[1, 32, 32, 32], device="cpu", seed=1)
+    g = torch.Generator().manual_seed(3)
+
+    def fake_grad(tr):       # gradients of the parameters only: the alignment padding of the arena stays zero
+        out = torch.zeros_like(tr.arena.grad)
+        for off, cnt in tr.arena.spans:
+            out[off:off + cnt] = torch.randn(cnt, generator=g) * 1e-2
+        return out
+
+    def fake_step(tr, lr):
+        tr.arena.grad.copy_(fake_grad(tr))
+        for gr in tr.opt.param_groups:
+            gr["lr"] = lr
+        tr.opt.step()
+        tr.global_step += 1
+
+    for lr in (1e-3, 2e-3, 3e-3):
+        fake_step(a, lr)
+    path = str(tmp_path / "lightning.ckpt")
+    a.save_checkpoint(path, lightning_layout=True)
+    ck = torch.load(path)
+    assert ck["epoch"] == 0 and ck["global_step"] == 3 and ck["lr_schedulers"][0]["last_epoch"] == 3
+    per = ck["optimizer_states"][0]
+    n = len(a.arena.params)
+    assert sorted(per["state"]) == list(range(n)) and per["param_groups"][0]["params"] == list(range(n))
+    assert all(tuple(per["state"][i]["exp_avg"].shape) == tuple(p.shape) for i, p in enumerate(a.arena.params))
+
+    # (1) a reference-style per-parameter Adam over copies of the parameters, loaded from the file
+    ref_params = [torch.nn.Parameter(p.detach().clone()) for p in a.arena.params]
+    ref = torch.optim.Adam(ref_params, lr=1.0, eps=1e-6, betas=(0.8, 0.9), weight_decay=a.weight_decay)
+    ref.load_state_dict(per)
+    # (2) another Trainer resumed from the file through the per-parameter path only
+    del ck["optimizer"]
+    torch.save(ck, path)
+    b = Trainer(cfg=cfg, image_size=[1, 32, 32, 32], device="cpu", seed=2)
+    b.load_checkpoint(path)
+    assert b.global_step == 3 and torch.equal(a.arena.flat, b.arena.flat)
+    sa, sb = a.opt.state_dict()["state"][0], b.opt.state_dict()["state"][0]
+    assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"])
+    assert float(sa["step"]) == float(sb["step"]) == 3.0
+
+    # the same fourth step on all three
+    grad = fake_grad(a)
+    for tr in (a, b):
+        tr.arena.grad.copy_(grad)
+        for gr in tr.opt.param_groups:
+            gr["lr"] = 2.5e-3
+        tr.opt.step()
+    for p, (off, cnt) in zip(ref_params, a.arena.spans):
+        p.grad = grad[off:off + cnt].view(p.shape).clone()
+    for gr in ref.param_groups:
+        gr["lr"] = 2.5e-3
+    ref.step()
+    assert torch.equal(a.arena.flat, b.arena.flat)
+    for p, q in zip(a.arena.params, ref_params):
+        assert torch.allclose(p, q, rtol=0, atol=1e-7), float((p - q).abs().max())
+
+    # state of a frozen parameter is refused
+    import pytest
+    c = Trainer(cfg=cfg, image_size=[1, 32, 32, 32], device="cpu", seed=4)
+    c.restore_encoder_only(path)
+    with pytest.raises(ValueError, match="frozen"):
+        c.load_optimizer_state_per_parameter(per)
