@@ -274,8 +274,11 @@ def main():
         staging = {"ms_per_step": ms2, "events_per_s": args.batch / (ms2 * 1e-3), "steps": k2,
                    "path": "pinned host larcv fp32 [B,1,M,4] -> H2D -> sei_larcv_to_scn on the device (copy stream, one batch ahead) -> train step"}
 
+    import ctypes
+    _h, _u = ctypes.c_int64(), ctypes.c_int64()
+    lib.sei_pool_stats(ctypes.byref(_h), ctypes.byref(_u))
+    pool_held = _h.value
     if rank == 0:
-        import ctypes
         roof = None
         if not args.no_prof:
             # dominant kernel: the gather->MFMA->LDS-accumulate conv kernel (forward launches + dX launches run the
@@ -371,7 +374,9 @@ def main():
                                       if tr.batch_rulebooks else "built lazily in the forward pass"))},
             "roofline": roof, "cpu_baseline": cpu,
             "hbm_peak_gb": {"torch_allocator": torch.cuda.max_memory_allocated() / 1e9,
-                            "torch_reserved": torch.cuda.max_memory_reserved() / 1e9},
+                            "torch_reserved": torch.cuda.max_memory_reserved() / 1e9,
+                            # the library's own device pool (hash tables, rulebooks, scratch): bytes held at the end
+                            "library_pool_held": pool_held / 1e9},
         }
         if sync is not None:
             out["data_parallel_checks"] = sync
