@@ -143,7 +143,7 @@ def test_overlapped_step_is_bit_identical_at_full_size():
     import sparseeventid_amd.scn as scn
     from bench import generate_batch
     from sparseeventid_amd.train import Trainer
-    data = [generate_batch(0, i, 4, (900, 900, 900), 50000 - 5000 * i, "tracks", 4) for i in range(3)]
+    data = [generate_batch(0, i, 4, (900, 900, 900), 50000 - 5000 * i, "tracks", 1) for i in range(3)]   # no fork: the GPU is initialised
     runs = {}
     for name in ("serial", "overlapped"):
         torch.manual_seed(99)
