@@ -47,7 +47,7 @@ def generate_batch(rank, batch_index, batch, grid, nvox, kind, workers):
     return arr, labels
 
 
-def cpu_baseline(arr, labels, image_size, n_events, fwd_only, threads=16, warmup=2, passes=5):
+def cpu_baseline(arr, labels, image_size, n_events, fwd_only, threads=16, warmup=2, passes=5, fwd_training=False):
     """Time the CPU restatement of the SCN-CPU algorithm (the SCN binary is unavailable) on the first `n_events`
     events of the same batch: C++/OpenMP inner loops (oracle/scn_omp.cpp: host hash + rule lists probed by all cores,
     per offset gather -> sgemm (OpenBLAS) -> scatter-add, two-pass BatchNorm, LeakyReLU) under the reference topology
@@ -74,7 +74,8 @@ def cpu_baseline(arr, labels, image_size, n_events, fwd_only, threads=16, warmup
         t0 = time.time()
         if fwd_only:
             with torch.no_grad():
-                dense = scn_cpu.encoder_forward(sd, cfg, (c, torch.from_numpy(f), b), image_size)
+                # inference as the reference runs it: eval-mode BatchNorm (running statistics), unless --fwd-bn train
+                dense = scn_cpu.encoder_forward(sd, cfg, (c, torch.from_numpy(f), b), image_size, training=fwd_training)
                 scn_cpu.head_forward(sd, dense, heads)
         else:
             dense = scn_cpu.encoder_forward(sd, cfg, (c, torch.from_numpy(f), b), image_size)
@@ -88,7 +89,8 @@ def cpu_baseline(arr, labels, image_size, n_events, fwd_only, threads=16, warmup
             "sample": "%d of the batch's events, %s, %d warm-up + %d timed passes (median %.1f s, all %s); C++/OpenMP "
                       "restatement of the SparseConvNet-CPU algorithm: per offset gather -> sgemm (%s) -> scatter-add, "
                       "OpenMP rule lists / BatchNorm / LeakyReLU (SCN binary unavailable)"
-                      % (n_events, "fwd" if fwd_only else "fwd+bwd", warmup, passes, dt,
+                      % (n_events, ("fwd (batch-statistics BatchNorm)" if fwd_training else "fwd (eval-mode BatchNorm)")
+                         if fwd_only else "fwd+bwd", warmup, passes, dt,
                          "/".join("%.1f" % t for t in times),
                          "OpenBLAS from the scipy wheel" if info["blas"] else "plain loops, no BLAS found")}
 
@@ -122,6 +124,10 @@ def main():
     ap.add_argument("--prefetch", dest="prefetch", action="store_true", default=True,
                     help="(default) step i+1's InputLayer hash + rulebooks are built on a side stream WHILE step i computes "
                     "(Trainer.prefetch(after=event)): once per step, inside the timed region; 353.7 -> 349.5 ms per step")
+    ap.add_argument("--fwd-bn", choices=["eval", "train"], default="eval",
+                    help="--mode fwd only: BatchNorm as the reference's inference path runs it (bin/exec.py:206-224 -> "
+                    "trainer.validate -> model.eval(): running statistics; conv + BN + residual + activation are then ONE "
+                    "kernel, sei_conv_bn_inference), or 'train': batch statistics under no_grad (rounds 1-2 measured this)")
     ap.add_argument("--no-prefetch", dest="prefetch", action="store_false",
                     help="rulebooks at the top of the forward pass instead (Trainer.batch_rulebooks)")
     args = ap.parse_args()
@@ -179,6 +185,9 @@ def main():
     inputs_ready = torch.cuda.Event()
     inputs_ready.record()
     staged = [tr.prefetch(image, after=inputs_ready) if prefetch else image]
+
+    if args.mode == "fwd" and args.fwd_bn == "eval":
+        tr.encoder.eval(); tr.head.eval()
 
     def step():
         if args.mode == "train":
@@ -348,7 +357,7 @@ def main():
         cpu = None
         if world == 1 and args.cpu_events > 0 and args.model == "dune3d":
             cpu = cpu_baseline(arr, labels, image_size, min(args.cpu_events, args.batch), args.mode == "fwd",
-                               args.cpu_threads)
+                               args.cpu_threads, fwd_training=args.fwd_bn == "train")
         out = {
             "metric": ("events/sec (fwd+bwd) DUNE-3D sparse ResNet, 64-event batch, 1/2/4/8 MI355X"
                        if args.mode == "train" else "events/sec (fwd only) DUNE-3D sparse ResNet")
@@ -362,7 +371,9 @@ def main():
                                       if args.model == "dune3d" else
                                       "sbnd 2-D multiplane shared-weight sparse ResNet (depth 6, pre-merge 3, 32 filters, "
                                       "2 res-blocks/level; voxels = pixels per plane)",
-                                      "fwd+bwd+Adam" if args.mode == "train" else "fwd", args.batch, args.voxels,
+                                      "fwd+bwd+Adam" if args.mode == "train" else
+                                      ("fwd (inference: eval-mode BatchNorm)" if args.fwd_bn == "eval" else "fwd (batch-statistics BatchNorm)"),
+                                      args.batch, args.voxels,
                                       grid[0], grid[1], grid[2], args.kind),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                        "backward": {0: "dX and dW back to back", 1: "dX and dW of a layer on two streams, joined per layer",

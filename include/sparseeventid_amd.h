@@ -166,6 +166,15 @@ int sei_conv_bn_forward(sei_rulebook_t *rb, const float *X, const float *W, cons
                         int32_t nIn, int32_t nOut, const float *gamma, const float *beta, float *running_mean,
                         float *running_var, float eps, float momentum, int32_t training, float leak,
                         const float *residual, float *Ybn, float *save_mean, float *save_invstd, sei_stream_t stream);
+
+/* Inference (eval-mode BatchNorm, no autograd): Y = LeakyReLU_leak(BN_running(conv(X)) (+ residual)) in ONE kernel -- the
+ * normalisation, the residual add and the activation are applied while the convolution kernel writes its finished tile,
+ * so the convolution output itself never reaches memory and no statistics are computed (the reference's inference path:
+ * bin/exec.py:206-224 -> trainer.validate -> model.eval()).  Same expression as the two-pass eval path of
+ * sei_conv_bn_forward(training = 0): bit-identical results.  gamma / beta / bias / residual may be NULL. */
+int sei_conv_bn_inference(sei_rulebook_t *rb, const float *X, const float *W, const float *bias, int32_t nIn, int32_t nOut,
+                          const float *gamma, const float *beta, const float *running_mean, const float *running_var,
+                          float eps, float leak, const float *residual, float *Y, sei_stream_t stream);
 /* backward of the above (training statistics): needs x, y (for the activation sign), dy.
  * dx [n,C]; dresidual [n,C] or NULL; dgamma/dbeta [C] or NULL. */
 int sei_bn_backward(const float *x, const float *y, const float *dy, int64_t n, int32_t C,

@@ -49,6 +49,8 @@ _SIGNATURES = {
                                       ctypes.c_int32, ctypes.c_float, vp, vp, vp, vp, vp]),
     "sei_conv_bn_forward": (ctypes.c_int, [vp, vp, vp, vp, vp, ctypes.c_int32, ctypes.c_int32, vp, vp, vp, vp, ctypes.c_float,
                                            ctypes.c_float, ctypes.c_int32, ctypes.c_float, vp, vp, vp, vp, vp]),
+    "sei_conv_bn_inference": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int32, ctypes.c_int32, vp, vp, vp, vp, ctypes.c_float,
+                                             ctypes.c_float, vp, vp, vp]),
     "sei_bn_backward": (ctypes.c_int, [vp, vp, vp, ctypes.c_int64, ctypes.c_int32, vp, vp, vp, ctypes.c_float,
                                        ctypes.c_int32, vp, vp, vp, vp, vp]),
     "sei_bn_backward_colsum": (ctypes.c_int, [vp, vp, vp, ctypes.c_int64, ctypes.c_int32, vp, vp, vp, vp, ctypes.c_float,

@@ -570,7 +570,8 @@ struct AlignedArg {
 
 // forward convolution; stats_out / parts_out (optional): BatchNorm partial sums of Y from the kernel epilogue
 static int conv_forward_impl(sei_rulebook_t *rb, const float *X, const float *W, const float *bias, float *Y, int32_t nIn,
-                             int32_t nOut, hipStream_t st, double **stats_out, int64_t *parts_out) {
+                             int32_t nOut, hipStream_t st, double **stats_out, int64_t *parts_out,
+                             const ConvEpilogue *ep = nullptr) {
     if (!rb) SEI_FAIL("null rulebook");
     note_stream(st);
     const TiledRules *t;
@@ -596,7 +597,7 @@ static int conv_forward_impl(sei_rulebook_t *rb, const float *X, const float *W,
             W = aw.p;
         }
         ProfScope ps(kind, st, 2.0 * t->n_rules * nIn * nOut, conv_bytes(*t, nIn, nOut));
-        return conv_forward(*t, X, W, bias, Y, nIn, nOut, st, nullptr, stats);
+        return conv_forward(*t, X, W, bias, Y, nIn, nOut, st, nullptr, stats, ep);
     }
     // the workgroup-tile MFMA kernel reads B operands with wide LDS loads from column-permuted weights (tiny copy, <= 4 MB)
     float *Wp;
@@ -604,7 +605,7 @@ static int conv_forward_impl(sei_rulebook_t *rb, const float *X, const float *W,
     int rc = conv_transform_weights(W, Wp, t->K, nIn, nOut, false, false, p.col_group, p.blocks, st);
     if (!rc) {
         ProfScope ps(kind, st, 2.0 * t->n_rules * nIn * nOut, conv_bytes(*t, nIn, nOut));
-        rc = conv_forward(*t, X, Wp, bias, Y, nIn, nOut, st, nullptr, stats);
+        rc = conv_forward(*t, X, Wp, bias, Y, nIn, nOut, st, nullptr, stats, ep);
     }
     pool_free(Wp);
     return rc;
@@ -628,6 +629,44 @@ int sei_conv_bn_forward(sei_rulebook_t *rb, const float *X, const float *W, cons
         rc = bn_forward(Yconv, rb->lout ? rb->lout->n : 0, nOut, gamma, beta, running_mean, running_var, eps, momentum,
                         training, leak, residual, Ybn, save_mean, save_invstd, st, stats, parts);
     pool_free(stats);
+    return rc;
+}
+
+int sei_conv_bn_inference(sei_rulebook_t *rb, const float *X, const float *W, const float *bias, int32_t nIn, int32_t nOut,
+                          const float *gamma, const float *beta, const float *running_mean, const float *running_var,
+                          float eps, float leak, const float *residual, float *Y, sei_stream_t stream) {
+    if (!rb) SEI_FAIL("null rulebook");
+    if (!running_mean || !running_var) SEI_FAIL("sei_conv_bn_inference: eval-mode BatchNorm needs running statistics");
+    hipStream_t st = (hipStream_t)stream;
+    note_stream(st);
+    const int64_t n = rb->lout ? rb->lout->n : 0;
+    if (n == 0) return 0;
+    const TiledRules *t;
+    const ConvPlan p = plan_conv(nIn, nOut, rulebook_K(rb), n);
+    SEI_TRY(get_tiled(rb, false, p.tile_rows, &t, st));
+    float *ms;   // [mean | invstd], 16-byte aligned for the epilogue's float4 loads
+    const int Cp = (nOut + 3) & ~3;
+    SEI_TRY(pool_alloc_t(&ms, 2 * (size_t)Cp, st));
+    int rc = bn_eval_stats(running_mean, running_var, eps, nOut, ms, ms + Cp, st);
+    const bool fused = conv_epilogue_supported(nIn, nOut, rulebook_K(rb), n, *t) && (((uintptr_t)residual | (uintptr_t)Y) & 15) == 0;
+    if (!rc && fused) {
+        AlignedArg ag, ab;
+        rc = ag.stage(gamma, nOut, st);
+        if (!rc) rc = ab.stage(beta, nOut, st);
+        ConvEpilogue ep;
+        ep.mean = ms; ep.invstd = ms + Cp; ep.gamma = ag.p; ep.beta = ab.p; ep.res = residual; ep.leak = leak;
+        if (!rc) rc = conv_forward_impl(rb, X, W, bias, Y, nIn, nOut, st, nullptr, nullptr, &ep);
+    } else if (!rc) {
+        // plans without the epilogue (scalar kernels of odd plane counts, the opt-in row-band family): two passes
+        float *yc;
+        rc = pool_alloc_t(&yc, (size_t)n * nOut, st);
+        if (!rc) rc = conv_forward_impl(rb, X, W, bias, yc, nIn, nOut, st, nullptr, nullptr);
+        if (!rc)
+            rc = bn_forward(yc, n, nOut, gamma, beta, const_cast<float *>(running_mean), const_cast<float *>(running_var), eps,
+                            0.f, 0, leak, residual, Y, ms, ms + Cp, st, nullptr, 0);
+        pool_free(yc);
+    }
+    pool_free(ms);
     return rc;
 }
 

@@ -274,10 +274,35 @@ bool plan_band(int nIn, int nOut, int K, int64_t n_dst, ConvPlan *p);
 // stats (optional, MFMA kernels only): per-(tile, part) column sums of the OUTPUT rows, [n_parts][2][nOut] doubles
 // (sum, sum of squares) accumulated in the kernel epilogue from the LDS tile -- BatchNorm statistics without a second
 // read of the conv output.  conv_stats_parts() = how many parts this plan writes (0: the plan cannot).
+// Inference epilogue (eval-mode BatchNorm + residual + LeakyReLU applied while the finished tile is written): the rows go
+// out as  leaky((y - mean) * (invstd * gamma) + beta (+ res))  -- the expression of bn_apply_kernel, so that the fused
+// write equals the two-pass result bit for bit -- and the convolution output itself never reaches memory.
+struct ConvEpilogue {
+    const float *mean = nullptr, *invstd = nullptr, *gamma = nullptr, *beta = nullptr, *res = nullptr;
+    float leak = 1.f;
+};
+__device__ __forceinline__ float4 conv_epilogue_apply(const ConvEpilogue &ep, float4 v, int c, const float *res_row) {
+    const float4 mu = *reinterpret_cast<const float4 *>(ep.mean + c);
+    const float4 is = *reinterpret_cast<const float4 *>(ep.invstd + c);
+    const float4 ga = ep.gamma ? *reinterpret_cast<const float4 *>(ep.gamma + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 be = ep.beta ? *reinterpret_cast<const float4 *>(ep.beta + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float z[4] = {(v.x - mu.x) * (is.x * ga.x) + be.x, (v.y - mu.y) * (is.y * ga.y) + be.y,
+                  (v.z - mu.z) * (is.z * ga.z) + be.z, (v.w - mu.w) * (is.w * ga.w) + be.w};
+    if (res_row) {
+        const float4 r = *reinterpret_cast<const float4 *>(res_row + c);
+        z[0] += r.x; z[1] += r.y; z[2] += r.z; z[3] += r.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) z[i] = z[i] > 0.f ? z[i] : z[i] * ep.leak;
+    return make_float4(z[0], z[1], z[2], z[3]);
+}
+// ep (optional): kinds 1 and 2 and the small-nIn kernel only -- conv_epilogue_supported() says whether a plan takes it
+bool conv_epilogue_supported(int nIn, int nOut, int K, int64_t n_dst, const TiledRules &t);
 int conv_forward(const TiledRules &t, const float *X, const float *W, const float *bias, float *Y, int nIn, int nOut,
-                 hipStream_t st, const float *init = nullptr, double *stats = nullptr);
+                 hipStream_t st, const float *init = nullptr, double *stats = nullptr, const ConvEpilogue *ep = nullptr);
 int conv_forward_wave(const TiledRules &t, const ConvPlan &p, const float *X, const float *W, const float *bias, float *Y,
-                      int nIn, int nOut, const float *init, double *stats, hipStream_t st);
+                      int nIn, int nOut, const float *init, double *stats, hipStream_t st,
+                      const ConvEpilogue &ep = ConvEpilogue{});
 int conv_forward_band(const TiledRules &t, const ConvPlan &p, const float *X, const float *W, const float *bias, float *Y,
                       int nIn, int nOut, const float *init, double *stats, hipStream_t st);
 int64_t conv_stats_parts(const ConvPlan &p, const TiledRules &t);
@@ -290,6 +315,8 @@ int conv_backward_weight(const TiledRules &t, const float *X, const float *dY, f
 // elementwise.hip
 int colsum(const float *x, int64_t n, int C, float *out, hipStream_t st);
 // stats / n_parts: precomputed partial sums of x (conv epilogue) -- training mode then skips its own reduction pass
+// eval-mode statistics: mean = running_mean, invstd = 1 / sqrt(running_var + eps) (the values bn_forward's eval path uses)
+int bn_eval_stats(const float *rmean, const float *rvar, float eps, int C, float *mean, float *invstd, hipStream_t st);
 int bn_forward(const float *x, int64_t n, int C, const float *gamma, const float *beta, float *rmean, float *rvar,
                float eps, float momentum, int training, float leak, const float *residual, float *y, float *save_mean,
                float *save_invstd, hipStream_t st, const double *stats = nullptr, int64_t n_parts = 0);

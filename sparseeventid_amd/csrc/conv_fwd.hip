@@ -128,7 +128,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : occ_for(MAXS, NT, SLJ))) vo
     const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ Y,
     const int32_t *__restrict__ tile_sub_start, const int32_t *__restrict__ tile_seg,
     const int32_t *__restrict__ sub_src, const uint8_t *__restrict__ sub_dst, int64_t n_dst, int K, int CIN, int n_tiles,
-    const float *__restrict__ init, int ldy, int blocks, double *__restrict__ stats) {
+    const float *__restrict__ init, int ldy, int blocks, double *__restrict__ stats, ConvEpilogue ep) {
     extern __shared__ float lds[];
     constexpr int U = NW / CS;  // units (groups of CS waves) dealing sub-chunks
     constexpr int TR = 16 * MAXS * U;
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : occ_for(MAXS, NT, SLJ))) vo
     }
     __syncthreads();
     const int64_t row0 = (int64_t)tile * TR;
-    tile_store<TR, COUT, 64 * NW>(acc_tile, Y, row0, n_dst, ldy, ycol0);
+    tile_store<TR, COUT, 64 * NW>(acc_tile, Y, row0, n_dst, ldy, ycol0, ep);
     if (stats) tile_stats<TR, COUT, 64 * NW>(acc_tile, stats, tile, row0, n_dst, ldy, ycol0);
     STAMP(11);
     STAMP_ADD(7, 1);
@@ -338,7 +338,8 @@ template <int CIN, int COUT>
 __global__ __launch_bounds__(256) void conv_tile_smallcin_kernel(
     const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ Y,
     const int32_t *__restrict__ tile_sub_start, const int32_t *__restrict__ tile_seg,
-    const int32_t *__restrict__ sub_src, const uint8_t *__restrict__ sub_dst, int64_t n_dst, int K, int TR) {
+    const int32_t *__restrict__ sub_src, const uint8_t *__restrict__ sub_dst, int64_t n_dst, int K, int TR,
+    ConvEpilogue ep) {
     extern __shared__ float lds[];
     float *acc = lds;                       // [TR][COUT]
     float *wl = lds + (size_t)TR * COUT;    // [K][CIN][COUT]
@@ -415,6 +416,18 @@ __global__ __launch_bounds__(256) void conv_tile_smallcin_kernel(
     }
     __syncthreads();
     const int64_t row0 = (int64_t)tile * TR;
+    if (ep.mean) {  // inference: eval-mode BatchNorm (+ residual) + LeakyReLU on the way out (common.h)
+        constexpr int V = COUT >> 2;
+        for (int idx = threadIdx.x; idx < TR * V; idx += 256) {
+            const int r = idx / V, v = idx - r * V;
+            if (row0 + r < n_dst) {
+                const float4 a = *reinterpret_cast<const float4 *>(acc + (size_t)r * COUT + 4 * v);
+                *reinterpret_cast<float4 *>(Y + (size_t)(row0 + r) * COUT + 4 * v) =
+                    conv_epilogue_apply(ep, a, 4 * v, ep.res ? ep.res + (size_t)(row0 + r) * COUT : nullptr);
+            }
+        }
+        return;
+    }
     for (int idx = threadIdx.x; idx < TR * COUT; idx += 256) {
         int r = idx / COUT;
         if (row0 + r < n_dst) Y[(size_t)row0 * COUT + idx] = acc[idx];
@@ -566,40 +579,40 @@ ConvPlan plan_conv(int nIn, int nOut, int K, int64_t n_dst) {
 
 template <int NT, int CS, int SLJ, int MAXS, int NW = 4>
 static int launch_mfma(const TiledRules &t, const ConvPlan &p, const float *X, const float *W, const float *bias,
-                       float *Y, int nIn, const float *init, double *stats, hipStream_t st) {
+                       float *Y, int nIn, const float *init, double *stats, hipStream_t st, const ConvEpilogue &ep) {
     SEI_TRY(ensure_max_lds((const void *)conv_tile_mfma_kernel<NT, CS, SLJ, MAXS, NW>, 160 * 1024));
     conv_tile_mfma_kernel<NT, CS, SLJ, MAXS, NW><<<((t.n_tiles * p.blocks + 7) / 8) * 8, 64 * NW, p.lds_bytes, st>>>(
         X, W, bias, Y, t.tile_sub_start, t.tile_seg, t.sub_src, t.sub_dst, t.n_dst, t.K, nIn, t.n_tiles, init,
-        NT * CS * 16 * p.blocks, p.blocks, stats);
+        NT * CS * 16 * p.blocks, p.blocks, stats, ep);
     SEI_LAUNCH_CHECK();
     return 0;
 }
 
 #define FWD_CASE(NT_, CS_, SLJ_, MAXS_)                                            \
     if (p.nt == NT_ && p.cs == CS_ && p.slj == SLJ_ && p.maxs == MAXS_ && p.nw == 4) \
-        return launch_mfma<NT_, CS_, SLJ_, MAXS_>(t, p, X, W, bias, Y, nIn, init, stats, st);
+        return launch_mfma<NT_, CS_, SLJ_, MAXS_>(t, p, X, W, bias, Y, nIn, init, stats, st, epv);
 #ifdef SEI_EXPERIMENTS
 #define FWD_CASE8(NT_)                                                             \
     if (p.nt == NT_ && p.cs == 1 && p.maxs == 1 && p.nw == 8) {                    \
-        if (p.slj == 2) return launch_mfma<NT_, 1, 2, 1, 8>(t, p, X, W, bias, Y, nIn, init, stats, st); \
-        return launch_mfma<NT_, 1, 1, 1, 8>(t, p, X, W, bias, Y, nIn, init, stats, st);                 \
+        if (p.slj == 2) return launch_mfma<NT_, 1, 2, 1, 8>(t, p, X, W, bias, Y, nIn, init, stats, st, epv); \
+        return launch_mfma<NT_, 1, 1, 1, 8>(t, p, X, W, bias, Y, nIn, init, stats, st, epv);                 \
     }
 #else
 #define FWD_CASE8(NT_)                                                             \
     if (p.nt == NT_ && p.cs == 1 && p.maxs == 1 && p.nw == 8 && p.slj == 1)        \
-        return launch_mfma<NT_, 1, 1, 1, 8>(t, p, X, W, bias, Y, nIn, init, stats, st);
+        return launch_mfma<NT_, 1, 1, 1, 8>(t, p, X, W, bias, Y, nIn, init, stats, st, epv);
 #endif
 #define FWD_CASE8S2(NT_)                                                           \
     if (p.nt == NT_ && p.cs == 1 && p.maxs == 1 && p.nw == 8 && p.slj == 2)        \
-        return launch_mfma<NT_, 1, 2, 1, 8>(t, p, X, W, bias, Y, nIn, init, stats, st);
+        return launch_mfma<NT_, 1, 2, 1, 8>(t, p, X, W, bias, Y, nIn, init, stats, st, epv);
 #define FWD_CASE8M2(NT_)                                                           \
     if (p.nt == NT_ && p.cs == 1 && p.maxs == 2 && p.nw == 8) {                    \
-        if (p.slj == 2) return launch_mfma<NT_, 1, 2, 2, 8>(t, p, X, W, bias, Y, nIn, init, stats, st); \
-        return launch_mfma<NT_, 1, 1, 2, 8>(t, p, X, W, bias, Y, nIn, init, stats, st);                 \
+        if (p.slj == 2) return launch_mfma<NT_, 1, 2, 2, 8>(t, p, X, W, bias, Y, nIn, init, stats, st, epv); \
+        return launch_mfma<NT_, 1, 1, 2, 8>(t, p, X, W, bias, Y, nIn, init, stats, st, epv);                 \
     }
 #define FWD_CASE8C(NT_)                                                            \
     if (p.nt == NT_ && p.cs == 2 && p.maxs == 2 && p.nw == 8 && p.slj == 2)       \
-        return launch_mfma<NT_, 2, 2, 2, 8>(t, p, X, W, bias, Y, nIn, init, stats, st);
+        return launch_mfma<NT_, 2, 2, 2, 8>(t, p, X, W, bias, Y, nIn, init, stats, st, epv);
 #define FWD_BOTH_SLJ(NT_, CS_, MAXS_) FWD_CASE(NT_, CS_, 1, MAXS_) FWD_CASE(NT_, CS_, 2, MAXS_)
 
 int64_t conv_stats_parts(const ConvPlan &p, const TiledRules &t) {
@@ -619,10 +632,22 @@ int64_t conv_stats_parts(const ConvPlan &p, const TiledRules &t) {
     return 0;
 }
 
+// which plans apply an inference epilogue in their store: the MFMA tile and wave kernels and the small-nIn (stem) kernel
+bool conv_epilogue_supported(int nIn, int nOut, int K, int64_t n_dst, const TiledRules &t) {
+    if (t.n_dst == 0 || t.n_sub == 0 || nOut % 4) return false;
+    const ConvPlan p = plan_conv(nIn, nOut, K, n_dst);
+    if (p.kind == 1 || p.kind == 2) return true;
+    if (p.kind != 0) return false;
+    return nIn <= 4 && (nOut == 16 || nOut == 32 || nOut == 64) && t.K + 1 <= 128 && t.tile_rows % 4 == 0 &&
+           ((size_t)t.tile_rows * nOut + (size_t)t.K * nIn * nOut) * sizeof(float) <= 160 * 1024;
+}
+
 int conv_forward(const TiledRules &t, const float *X, const float *W, const float *bias, float *Y, int nIn, int nOut,
-                 hipStream_t st, const float *init, double *stats) {
+                 hipStream_t st, const float *init, double *stats, const ConvEpilogue *ep) {
     if (t.n_dst == 0) return 0;
     if (init && bias) SEI_FAIL("conv_forward: bias and init are mutually exclusive");
+    if (ep && !conv_epilogue_supported(nIn, nOut, t.K, t.n_dst, t)) SEI_FAIL("conv_forward: this plan takes no inference epilogue");
+    const ConvEpilogue epv = ep ? *ep : ConvEpilogue{};
     if (t.n_sub == 0 && !init) {
         int64_t tot = t.n_dst * nOut;
         fill_bias_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, st>>>(Y, t.n_dst, nOut, bias);
@@ -633,7 +658,7 @@ int conv_forward(const TiledRules &t, const float *X, const float *W, const floa
     if (init && (p.kind == 0 || t.n_sub == 0)) SEI_FAIL("conv_forward: init is only supported by the MFMA kernels");
     if (p.tile_rows != t.tile_rows) SEI_FAIL("conv_forward: rulebook tile size does not match the kernel plan");
     if (stats && (p.kind == 0 || t.n_sub == 0)) SEI_FAIL("conv_forward: statistics are only produced by the MFMA kernels");
-    if (p.kind == 2) return conv_forward_wave(t, p, X, W, bias, Y, nIn, nOut, init, stats, st);
+    if (p.kind == 2) return conv_forward_wave(t, p, X, W, bias, Y, nIn, nOut, init, stats, st, epv);
     if (p.kind == 3) return conv_forward_band(t, p, X, W, bias, Y, nIn, nOut, init, stats, st);
     if (p.kind == 1) {
         // eight-wave workgroups: 96 columns in one block, 128 / 160 (and 96 behind a 16-plane input) in two column blocks
@@ -664,7 +689,7 @@ int conv_forward(const TiledRules &t, const float *X, const float *W, const floa
     do {                                                                                                           \
         SEI_TRY(ensure_max_lds((const void *)conv_tile_smallcin_kernel<CIN_, COUT_>, 160 * 1024));                 \
         conv_tile_smallcin_kernel<CIN_, COUT_><<<t.n_tiles, 256, lds_small, st>>>(                                 \
-            X, W, bias, Y, t.tile_sub_start, t.tile_seg, t.sub_src, t.sub_dst, t.n_dst, t.K, t.tile_rows);         \
+            X, W, bias, Y, t.tile_sub_start, t.tile_seg, t.sub_src, t.sub_dst, t.n_dst, t.K, t.tile_rows, epv);    \
     } while (0)
 #define SMFC(CIN_) do { if (nOut == 16) SMF(CIN_, 16); else if (nOut == 32) SMF(CIN_, 32); else SMF(CIN_, 64); } while (0)
             if (nIn == 1) SMFC(1); else if (nIn == 2) SMFC(2); else if (nIn == 3) SMFC(3); else SMFC(4);

@@ -94,8 +94,19 @@ __device__ __forceinline__ void band_init(float *acc_tile, const float *__restri
 // statistics of the output from the LDS band (see conv_tile.h: tile_stats): [tile * PARTS + part][2][ldy] doubles
 template <int NC>
 __device__ __forceinline__ void band_store(const float *acc_tile, float *__restrict__ Y, double *__restrict__ stats, int tile,
-                                           int64_t row0, int TR, int64_t n_dst, int ldy, int col0, int lane) {
+                                           int64_t row0, int TR, int64_t n_dst, int ldy, int col0, int lane,
+                                           const ConvEpilogue &ep = ConvEpilogue{}) {
     constexpr int V = NC >> 2;
+    if (ep.mean) {  // inference epilogue (common.h)
+        for (int idx = lane; idx < TR * V; idx += 64) {
+            const int r = idx / V, v = idx - r * V;
+            if (row0 + r < n_dst) {
+                const float4 a = *reinterpret_cast<const float4 *>(acc_tile + (size_t)r * NC + 4 * v);
+                *reinterpret_cast<float4 *>(Y + (size_t)(row0 + r) * ldy + col0 + 4 * v) =
+                    conv_epilogue_apply(ep, a, col0 + 4 * v, ep.res ? ep.res + (size_t)(row0 + r) * ldy : nullptr);
+            }
+        }
+    } else
     for (int idx = lane; idx < TR * V; idx += 64) {
         const int r = idx / V, v = idx - r * V;
         if (row0 + r < n_dst)

@@ -82,8 +82,19 @@ __device__ __forceinline__ void tile_init(float *acc_tile, const float *__restri
 // every dst row is written once, as whole float4 row segments
 template <int TR, int COUT, int NTH = 256>
 __device__ __forceinline__ void tile_store(const float *acc_tile, float *__restrict__ Y, int64_t row0, int64_t n_dst, int ldy,
-                                           int ycol0) {
+                                           int ycol0, const ConvEpilogue &ep = ConvEpilogue{}) {
     constexpr int V = COUT >> 2;
+    if (ep.mean) {  // inference: eval-mode BatchNorm (+ residual) + LeakyReLU on the way out (common.h)
+        for (int idx = threadIdx.x; idx < TR * V; idx += NTH) {
+            int r = idx / V, v = idx - r * V;
+            if (row0 + r < n_dst) {
+                const float4 a = *reinterpret_cast<const float4 *>(acc_tile + (size_t)r * COUT + 4 * v);
+                *reinterpret_cast<float4 *>(Y + (size_t)(row0 + r) * ldy + ycol0 + 4 * v) =
+                    conv_epilogue_apply(ep, a, ycol0 + 4 * v, ep.res ? ep.res + (size_t)(row0 + r) * ldy : nullptr);
+            }
+        }
+        return;
+    }
     for (int idx = threadIdx.x; idx < TR * V; idx += NTH) {
         int r = idx / V, v = idx - r * V;
         if (row0 + r < n_dst)

@@ -199,7 +199,7 @@ __global__ __launch_bounds__(64, wave_occ(NT, G)) void conv_wave_mfma_kernel(
     const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ Y,
     const int32_t *__restrict__ tile_sub_start, const int32_t *__restrict__ tile_seg,
     const int32_t *__restrict__ sub_src, const uint8_t *__restrict__ sub_dst, int64_t n_dst, int K, int CIN, int n_tiles,
-    const float *__restrict__ init, int ldy, int blocks, int TR, double *__restrict__ stats) {
+    const float *__restrict__ init, int ldy, int blocks, int TR, double *__restrict__ stats, ConvEpilogue ep) {
     extern __shared__ float lds[];
     constexpr int NC = 16 * NT;  // columns of this wave = LDS row stride
     // work item = (tile, column block) in the XCD-aware order of xcd_item (conv_tile.h): neighbouring tiles and the column
@@ -304,6 +304,16 @@ __global__ __launch_bounds__(64, wave_occ(NT, G)) void conv_wave_mfma_kernel(
     // epilogue: every dst row is written once, as whole float4 row segments
     constexpr int V = NC >> 2;
     const int64_t row0 = (int64_t)tile * TR;
+    if (ep.mean) {  // inference: eval-mode BatchNorm (+ residual) + LeakyReLU on the way out (common.h)
+        for (int idx = lane; idx < TR * V; idx += 64) {
+            const int r = idx / V, v = idx - r * V;
+            if (row0 + r < n_dst) {
+                const float4 a = *reinterpret_cast<const float4 *>(acc_tile + (size_t)r * NC + 4 * v);
+                *reinterpret_cast<float4 *>(Y + (size_t)(row0 + r) * ldy + col0 + 4 * v) =
+                    conv_epilogue_apply(ep, a, col0 + 4 * v, ep.res ? ep.res + (size_t)(row0 + r) * ldy : nullptr);
+            }
+        }
+    } else
     for (int idx = lane; idx < TR * V; idx += 64) {
         const int r = idx / V, v = idx - r * V;
         if (row0 + r < n_dst)
@@ -397,20 +407,20 @@ bool plan_wave(int nIn, int nOut, int K, int64_t n_dst, ConvPlan *p) {
 
 template <int NT, int G>
 static int launch_wave(const TiledRules &t, const ConvPlan &p, const float *X, const float *W, const float *bias, float *Y,
-                       int nIn, int nOut, const float *init, double *stats, hipStream_t st) {
+                       int nIn, int nOut, const float *init, double *stats, hipStream_t st, const ConvEpilogue &ep) {
     const int nwork = t.n_tiles * p.blocks;
     conv_wave_mfma_kernel<NT, G><<<((nwork + 7) / 8) * 8, 64, p.lds_bytes, st>>>(
         X, W, bias, Y, t.tile_sub_start, t.tile_seg, t.sub_src, t.sub_dst, t.n_dst, t.K, nIn, t.n_tiles, init, nOut,
-        p.blocks, t.tile_rows, stats);
+        p.blocks, t.tile_rows, stats, ep);
     SEI_LAUNCH_CHECK();
     return 0;
 }
 
 #define WAVE_CASE(NT_, G_) \
-    if (p.nt == NT_ && p.g == G_) return launch_wave<NT_, G_>(t, p, X, W, bias, Y, nIn, nOut, init, stats, st);
+    if (p.nt == NT_ && p.g == G_) return launch_wave<NT_, G_>(t, p, X, W, bias, Y, nIn, nOut, init, stats, st, ep);
 
 int conv_forward_wave(const TiledRules &t, const ConvPlan &p, const float *X, const float *W, const float *bias, float *Y,
-                      int nIn, int nOut, const float *init, double *stats, hipStream_t st) {
+                      int nIn, int nOut, const float *init, double *stats, hipStream_t st, const ConvEpilogue &ep) {
     // defaults (32 / 64 columns) and the forced-kernel plans (any column count, groups of 2)
     WAVE_CASE(1, 2) WAVE_CASE(2, 2) WAVE_CASE(3, 2) WAVE_CASE(4, 2) WAVE_CASE(5, 2) WAVE_CASE(6, 2) WAVE_CASE(7, 2) WAVE_CASE(8, 2)
     WAVE_CASE(4, 3)

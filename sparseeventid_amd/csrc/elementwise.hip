@@ -357,6 +357,12 @@ __global__ void eval_stats_kernel(const float *rmean, const float *rvar, float e
     save_invstd[c] = 1.f / sqrtf(rvar[c] + eps);
 }
 
+int bn_eval_stats(const float *rmean, const float *rvar, float eps, int C, float *mean, float *invstd, hipStream_t st) {
+    eval_stats_kernel<<<(C + 63) / 64, 64, 0, st>>>(rmean, rvar, eps, C, mean, invstd);
+    SEI_LAUNCH_CHECK();
+    return 0;
+}
+
 static inline unsigned ew_blocks(int64_t total_vec) {
     int64_t b = (total_vec + 255) / 256;
     // grid-stride kernels: 3 workgroups per CU (768 on the 256-CU MI355X) measured best for the streaming BatchNorm /

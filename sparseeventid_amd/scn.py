@@ -452,9 +452,33 @@ class _ConvBN(torch.autograd.Function):
         return dx, None, dw, db, dg, dbe, None, None, None, None, None, None, dres
 
 
+def _inference(bn, *tensors):
+    """eval-mode BatchNorm and nothing to differentiate: the conv kernel applies BN / residual / activation in its store."""
+    if bn.training or bn.running_mean is None:
+        return False
+    if not torch.is_grad_enabled():
+        return True
+    return not any(t is not None and t.requires_grad for t in tensors)
+
+
+def _conv_bn_inference(x, rb, conv, bn, leak, residual):
+    nIn, nOut = conv.weight.shape[1], conv.weight.shape[2]
+    if x.shape[1] != nIn:
+        raise RuntimeError("convolution: input has %d planes, weight expects %d" % (x.shape[1], nIn))
+    if x.shape[0] != rb.n_src:
+        raise RuntimeError("convolution: %d feature rows but the metadata level has %d" % (x.shape[0], rb.n_src))
+    y = torch.empty((rb.n_dst, nOut), dtype=torch.float32, device=x.device)
+    check(lib().sei_conv_bn_inference(rb.h, _ptr(x), _ptr(conv.weight), _ptr(conv.bias), nIn, nOut, _ptr(bn.weight),
+                                      _ptr(bn.bias), _ptr(bn.running_mean), _ptr(bn.running_var), bn.eps, float(leak),
+                                      _ptr(residual), _ptr(y), _stream()))
+    return y
+
+
 def conv_bn_act(x, conv, bn, leak=1.0, residual=None):
     """Fused ``conv -> bn (+ residual) -> LeakyReLU(leak)`` on SparseConvNetTensor ``x`` (conv: SubmanifoldConvolution
-    or Convolution module, bn: BatchNormalization module); returns the SparseConvNetTensor of the result."""
+    or Convolution module, bn: BatchNormalization module); returns the SparseConvNetTensor of the result.  In eval mode
+    with nothing to differentiate (the reference's inference path, ``trainer.validate``) the whole chain is ONE kernel:
+    ``sei_conv_bn_inference``."""
     sp = _triple(x.spatial_size)
     if isinstance(conv, Convolution):
         rb = x.metadata.conv_rulebook(sp, conv.filter_size, conv.filter_stride)
@@ -462,6 +486,10 @@ def conv_bn_act(x, conv, bn, leak=1.0, residual=None):
     else:
         rb = x.metadata.subm_rulebook(sp, conv.filter_size)
         out = SparseConvNetTensor(metadata=x.metadata, spatial_size=x.spatial_size)
+    if _inference(bn, x.features, residual, conv.weight, conv.bias, bn.weight, bn.bias):
+        out.features = _conv_bn_inference(_f32c(x.features), rb, conv, bn, leak,
+                                          None if residual is None else _f32c(residual))
+        return out
     out.features = _ConvBN.apply(_f32c(x.features), rb, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean,
                                  bn.running_var, bn.eps, bn.momentum, bn.training, float(leak),
                                  None if residual is None else _f32c(residual))
@@ -479,6 +507,12 @@ def residual_block(x, conv1, bn1, conv2, bn2, leak1, leak2):
     sp = _triple(x.spatial_size)
     rb = x.metadata.subm_rulebook(sp, conv1.filter_size)
     out = SparseConvNetTensor(metadata=x.metadata, spatial_size=x.spatial_size)
+    if _inference(bn1, x.features, conv1.weight, conv1.bias, bn1.weight, bn1.bias, conv2.weight, conv2.bias, bn2.weight,
+                  bn2.bias) and not bn2.training and bn2.running_mean is not None:
+        xf = _f32c(x.features)
+        a1 = _conv_bn_inference(xf, rb, conv1, bn1, leak1, None)
+        out.features = _conv_bn_inference(a1, rb, conv2, bn2, leak2, xf)
+        return out
     out.features = _ResidualBlock.apply(_f32c(x.features), rb, conv1.weight, conv1.bias, bn1.weight, bn1.bias,
                                         bn1.running_mean, bn1.running_var, conv2.weight, conv2.bias, bn2.weight, bn2.bias,
                                         bn2.running_mean, bn2.running_var, (bn1.eps, bn1.momentum, bn1.training),

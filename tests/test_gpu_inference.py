@@ -1,0 +1,130 @@
+"""GPU: the inference path (eval-mode BatchNorm, nothing to differentiate -- the reference's `trainer.validate`,
+bin/exec.py:206-224): conv -> BN (+ residual) -> LeakyReLU is ONE kernel (sei_conv_bn_inference: the normalisation, the
+residual add and the activation are applied while the convolution kernel stores its finished tile).  It evaluates the
+same expression as the two-pass eval path (convolution, then the BatchNorm apply kernel), which the oracle tests cover:
+results must be bit-identical -- per block for every kernel family the plans use (wave 32 / 64 planes, tile 96-192
+planes, the small-nIn stem kernel, the strided convolution), for the two-pass fallback of plans without the epilogue,
+and for the whole network."""
+import pytest
+import torch
+
+from tests.util import blob_cloud
+
+pytestmark = pytest.mark.gpu
+
+
+def _params():
+    from sparseeventid_amd.config import Encoder
+    return Encoder()
+
+
+def _cloud(seed, B, sp, n, planes):
+    import sparseeventid_amd.scn as scn
+    coords, feats = blob_cloud(seed, B, sp, n, 1)
+    t = scn.InputLayer(3, sp)((torch.from_numpy(coords), torch.from_numpy(feats).cuda(), B))
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    t.features = torch.randn(t.features.shape[0], planes, device="cuda", generator=g)
+    return t
+
+
+def _randomise_bn(module, seed):
+    import sparseeventid_amd.scn as scn
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    with torch.no_grad():
+        for m in module.modules():
+            if isinstance(m, scn.BatchNormalization):
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, device="cuda", generator=g) * 0.3)
+                m.running_var.copy_(torch.rand(m.running_var.shape, device="cuda", generator=g) + 0.5)
+                if m.weight is not None:
+                    m.weight.copy_(torch.rand(m.weight.shape, device="cuda", generator=g) + 0.5)
+                    m.bias.copy_(torch.randn(m.bias.shape, device="cuda", generator=g) * 0.2)
+
+
+def _both_ways(module, t):
+    """eval mode: the differentiable path (two passes: conv, BN apply) and the inference path (one kernel)."""
+    import sparseeventid_amd.scn as scn
+    module.eval()
+    x = t.features
+    two = module(scn.SparseConvNetTensor(x.clone().requires_grad_(True), t.metadata, t.spatial_size))
+    with torch.no_grad():
+        one = module(scn.SparseConvNetTensor(x.clone(), t.metadata, t.spatial_size))
+    assert two.features.requires_grad and not one.features.requires_grad
+    return two.features.detach(), one.features
+
+
+@pytest.mark.parametrize("C", [32, 64, 96, 128, 160, 192])
+def test_residual_block_inference_is_bit_identical_to_the_two_pass_eval_path(C):
+    from sparseeventid_amd.networks import ResidualBlock
+    t = _cloud(3 + C, 3, [28, 26, 30], 2200, C)
+    assert t.features.shape[0] % 64 != 0
+    torch.manual_seed(C)
+    blk = ResidualBlock(nIn=C, nOut=C, dim=3, params=_params()).cuda()
+    _randomise_bn(blk, C)
+    two, one = _both_ways(blk, t)
+    assert torch.equal(two, one)
+    assert float(one.abs().max()) > 0 and bool((one < 0).any())      # LeakyReLU really applied to both signs
+
+
+def test_stem_block_and_downsample_inference():
+    """1 -> 32 planes 5^3 (the small-nIn kernel) and the strided 2^3 convolution 64 -> 96 (tile kernel, K = 8)."""
+    import sparseeventid_amd.scn as scn
+    from sparseeventid_amd.config import Encoder
+    from sparseeventid_amd.networks import Block, ConvolutionDownsample
+    t = _cloud(11, 2, [30, 30, 30], 2500, 1)
+    torch.manual_seed(1)
+    p = Encoder(filter_size=5)
+    stem = Block(nIn=1, nOut=32, dim=3, params=p).cuda()
+    _randomise_bn(stem, 5)
+    two, one = _both_ways(stem, t)
+    assert torch.equal(two, one)
+    t2 = _cloud(12, 2, [30, 30, 30], 2500, 64)
+    down = ConvolutionDownsample(nIn=64, nOut=96, dim=3, params=_params()).cuda()
+    _randomise_bn(down, 6)
+    two, one = _both_ways(down, t2)
+    assert torch.equal(two, one) and one.shape[1] == 96 and one.shape[0] < t2.features.shape[0]
+
+
+def test_inference_falls_back_to_two_passes_for_plans_without_the_epilogue(force_conv_kernel):
+    """Odd plane counts run the scalar kernels and a pinned row-band family has no epilogue: sei_conv_bn_inference then runs
+    the convolution into scratch and the BatchNorm apply kernel behind it -- same results."""
+    import sparseeventid_amd.scn as scn
+    t = _cloud(21, 2, [24, 24, 24], 1500, 20)
+    conv = scn.SubmanifoldConvolution(3, 20, 12, 3, True).cuda()
+    bn = scn.BatchNormalization(12).cuda()
+    _randomise_bn(bn, 9)
+    bn.eval()
+    xin = scn.SparseConvNetTensor(t.features.clone().requires_grad_(True), t.metadata, t.spatial_size)
+    two = scn.conv_bn_act(xin, conv, bn, 0.25).features.detach()
+    with torch.no_grad():
+        one = scn.conv_bn_act(scn.SparseConvNetTensor(t.features.clone(), t.metadata, t.spatial_size), conv, bn, 0.25).features
+    assert torch.equal(two, one)
+    t96 = _cloud(22, 2, [24, 24, 24], 1500, 96)
+    conv = scn.SubmanifoldConvolution(3, 96, 96, 3, False).cuda()
+    bn = scn.BatchNormalization(96).cuda()
+    _randomise_bn(bn, 10)
+    bn.eval()
+    res = {}
+    for fam in ("tile", "band"):
+        force_conv_kernel(fam)
+        with torch.no_grad():
+            res[fam] = scn.conv_bn_act(scn.SparseConvNetTensor(t96.features.clone(), t96.metadata, t96.spatial_size), conv, bn,
+                                       0.333, residual=t96.features).features
+    assert torch.equal(res["tile"], res["band"])
+
+
+def test_whole_network_inference_equals_the_differentiable_eval_forward():
+    from sparseeventid_amd.config import Config, Encoder
+    from sparseeventid_amd.networks import build_networks
+    cfg = Config(encoder=Encoder(depth=3, n_initial_filters=32, n_output_filters=32, blocks_per_layer=2))
+    torch.manual_seed(4)
+    enc, head = build_networks(cfg, [1, 64, 64, 64], {"labelneutID": 3, "labelprotID": 3})
+    enc.cuda().eval(); head.cuda().eval()
+    _randomise_bn(enc, 13)
+    coords, feats = blob_cloud(31, 3, [64, 64, 64], 3000, 1)
+    image = (torch.from_numpy(coords), torch.from_numpy(feats).cuda(), 3)
+    f2 = torch.from_numpy(feats).cuda().requires_grad_(True)
+    two = head(enc((torch.from_numpy(coords), f2, 3)))
+    with torch.no_grad():
+        one = head(enc(image))
+    for k in two:
+        assert torch.equal(two[k].detach(), one[k]), k

@@ -4,6 +4,7 @@
 mkdir -p gpurun_out/r03
 run() { name=$1; shift; timeout -k 10 400 python bench.py "$@" 2> gpurun_out/r03/$name.err | tail -1 > gpurun_out/r03/$name.json; echo "$name rc=$? $(python3 -c "import json;d=json.load(open('gpurun_out/r03/$name.json'));print(round(d['value'],1),'events/s',round(d['ms_per_step'],1),'ms', (d.get('roofline') or {}).get('frac'))" 2>&1)"; }
 run r03_bench_fwd32   --mode fwd --batch 32 --steps 10 --warmup 3 --cpu-events 8
+run r03_bench_fwd32_batchstats --mode fwd --batch 32 --steps 10 --warmup 3 --cpu-events 0 --fwd-bn train
 run r03_bench_sbnd    --model sbnd --batch 128 --steps 5 --warmup 2 --cpu-events 0
 run r03_bench_padded  --grid 1024 512 1280 --steps 5 --warmup 2 --cpu-events 0
 run r03_bench_uniform --kind uniform --steps 5 --warmup 2 --cpu-events 0
