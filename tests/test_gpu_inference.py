@@ -128,3 +128,42 @@ def test_whole_network_inference_equals_the_differentiable_eval_forward():
         one = head(enc(image))
     for k in two:
         assert torch.equal(two[k].detach(), one[k]), k
+
+
+def test_inference_forward_matches_the_oracle_in_eval_mode():
+    """The one-kernel inference path against the CPU restatement run with training=False (running statistics): dense
+    encoder output and logits within the forward tolerance of every other oracle test (1e-4, max-norm relative)."""
+    from oracle import scn_cpu
+    from sparseeventid_amd.config import Config, Encoder
+    from sparseeventid_amd.networks import build_networks
+    from tests.util import rel_err
+    heads = {"labelneutID": 3, "labelprotID": 3, "labelnpiID": 2, "labelcpiID": 2}
+    kw = dict(depth=2, n_initial_filters=32, n_output_filters=32, blocks_per_layer=2)
+    image_size = [1, 36, 28, 44]
+    ocfg = scn_cpu.NetConfig(dimension=3, **kw)
+    sd = scn_cpu.init_params(ocfg, seed=5, heads=heads)
+    g = torch.Generator().manual_seed(6)
+    for k in sd:
+        if k.endswith("norm.weight"):
+            sd[k] = 1 + 0.2 * torch.randn(sd[k].shape, generator=g)
+        if k.endswith("norm.bias") or k.endswith("conv1.bias") or k == "initial_convolution.bias":
+            sd[k] = 0.1 * torch.randn(sd[k].shape, generator=g)
+        if k.endswith("running_mean"):
+            sd[k] = 0.2 * torch.randn(sd[k].shape, generator=g)
+        if k.endswith("running_var"):
+            sd[k] = 0.5 + torch.rand(sd[k].shape, generator=g)
+    enc, head = build_networks(Config(encoder=Encoder(**kw)), image_size, heads)
+    enc.cuda(); head.cuda()
+    enc.load_state_dict({k: v for k, v in sd.items() if not k.startswith("classification_head")})
+    head.load_state_dict({k: v for k, v in sd.items() if k.startswith("classification_head")})
+    enc.eval(); head.eval()
+    B = 3
+    coords, feats = blob_cloud(78, B, image_size[1:], 500, 1)
+    with torch.no_grad():
+        dense = enc((torch.from_numpy(coords), torch.from_numpy(feats).cuda(), B))
+        logits = head(dense)
+        odense = scn_cpu.encoder_forward(sd, ocfg, (coords, torch.from_numpy(feats), B), image_size, training=False)
+        ologits = scn_cpu.head_forward(sd, odense, heads)
+    assert rel_err(dense, odense) < 1e-4
+    for k in heads:
+        assert rel_err(logits[k], ologits[k]) < 1e-4
