@@ -609,6 +609,55 @@ __global__ __launch_bounds__(256) void conv_dw_generic_kernel(
     }
 }
 
+// dW of a convolution with a FEW output planes (COUT <= 8: the 224 -> 2 / 3 class maps that end the SBND heads,
+// torch/sparseresnet.py:300-334): thread = input plane, the rule's COUT partial products in registers.  X rows are read
+// coalesced across the input planes, a rule's dY values are broadcast loads; slots are walked four at a time with their
+// loads issued together and their FMAs kept in slot order (fixed summation order).  One workgroup per (k, split) with
+// SMALL splits: the generic kernel below gave each of 672 (ci, co) threads a serial walk over a whole split of
+// uncoalesced loads -- 3.6 ms per launch, 14 ms of the SBND step for four 1 x 1 x 1 layers.
+template <int CO>
+__global__ __launch_bounds__(256) void conv_dw_narrow_kernel(
+    const float *__restrict__ X, const float *__restrict__ dY, const int32_t *__restrict__ tile_sub_start,
+    const int32_t *__restrict__ seg_start, const int32_t *__restrict__ sub_src, const uint8_t *__restrict__ sub_dst,
+    int n_tiles, int TR, int CIN, int COUT, int tiles_per_split, int S, float *__restrict__ slab) {
+    const int k = blockIdx.x, s = blockIdx.y;
+    const int t_begin = s * tiles_per_split;
+    const int t_end = min(n_tiles, t_begin + tiles_per_split);
+    float *out = slab + (size_t)(k * S + s) * CIN * COUT;
+    for (int ci = threadIdx.x; ci < CIN; ci += 256) {
+        float acc[CO];
+#pragma unroll
+        for (int c = 0; c < CO; c++) acc[c] = 0.f;
+        for (int t = t_begin; t < t_end; t++) {
+            const int64_t ca = (tile_sub_start[t] + (int64_t)seg_start[(size_t)k * n_tiles + t]) * SUB_SLOTS;
+            const int64_t cb = (tile_sub_start[t] + (int64_t)seg_start[(size_t)(k + 1) * n_tiles + t]) * SUB_SLOTS;
+            for (int64_t sl = ca; sl < cb; sl += 4) {   // sub-chunks hold 16 slots: groups of four never straddle one
+                int src[4];
+                float x[4], d[4][CO];
+#pragma unroll
+                for (int j = 0; j < 4; j++) src[j] = sub_src[sl + j];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int sv = src[j] > 0 ? src[j] : 0;   // clamped, never a branch around a load
+                    x[j] = X[(size_t)sv * CIN + ci];
+                    const float *dr = dY + ((size_t)t * TR + sub_dst[sl + j]) * COUT;
+#pragma unroll
+                    for (int c = 0; c < CO; c++) d[j][c] = c < COUT ? dr[c] : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (src[j] >= 0) {
+#pragma unroll
+                        for (int c = 0; c < CO; c++) acc[c] = fmaf(x[j], d[j][c], acc[c]);
+                    }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CO; c++)
+            if (c < COUT) out[(size_t)ci * COUT + c] = acc[c];
+    }
+}
+
 __global__ void slab_reduce_kernel(const float *__restrict__ slab, float *__restrict__ dW, int K, int S, int64_t per) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= K * per) return;
@@ -733,6 +782,7 @@ int conv_backward_weight(const TiledRules &t, const float *X, const float *dY, f
 #endif
     }
     bool small = !mfma_ok && nIn <= 4 && (nOut == 16 || nOut == 32 || nOut == 64);
+    const bool narrow = !mfma_ok && !small && nOut <= 8;   // a few output planes: conv_dw_narrow_kernel
     // splits: a split's dY / X rows (re-read by the K workgroups of that split, which share an XCD) should fit
     // that XCD's 4 MiB L2; bounded slab size; at least enough workgroups to fill 256 CUs
     // 3 MiB of rows per split; 1.5 MiB measured faster in the 16-event micro-benchmark but slower in the 64-event step
@@ -745,6 +795,7 @@ int conv_backward_weight(const TiledRules &t, const float *X, const float *dY, f
     int tps = (int)(rows_fit / t.tile_rows);
     if (tps > DW_TILES_PER_ITER) tps = DW_TILES_PER_ITER;
     if (tps < 8) tps = 8;
+    if (narrow) tps = 2;   // little work per rule: many small splits (the slab is K * S * nIn * nOut floats, tiny here)
     int S = (t.n_tiles + tps - 1) / tps;
     int64_t smax = (512ll << 20) / ((int64_t)t.K * per * 4);
     if (smax < 1) smax = 1;
@@ -775,6 +826,14 @@ int conv_backward_weight(const TiledRules &t, const float *X, const float *dY, f
         if (nIn == 1) { SMC(1); } else if (nIn == 2) { SMC(2); } else if (nIn == 3) { SMC(3); } else { SMC(4); }
 #undef SMC
 #undef SM
+        if (hipGetLastError() != hipSuccess) rc = 1;
+    } else if (narrow) {
+        if (nOut <= 4)
+            conv_dw_narrow_kernel<4><<<grid, 256, 0, st>>>(X, dY, t.tile_sub_start, t.seg_start, t.sub_src, t.sub_dst,
+                                                           t.n_tiles, t.tile_rows, nIn, nOut, tps, S, slab);
+        else
+            conv_dw_narrow_kernel<8><<<grid, 256, 0, st>>>(X, dY, t.tile_sub_start, t.seg_start, t.sub_src, t.sub_dst,
+                                                           t.n_tiles, t.tile_rows, nIn, nOut, tps, S, slab);
         if (hipGetLastError() != hipSuccess) rc = 1;
     } else {
         conv_dw_generic_kernel<<<grid, 256, 0, st>>>(X, dY, t.tile_sub_start, t.seg_start, t.sub_src, t.sub_dst,

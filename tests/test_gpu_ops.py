@@ -123,7 +123,7 @@ def test_strided_rulebook_exact(sp, size, stride):
 
 CONV_CASES = [(1, 32, [5, 5, 5]), (32, 32, [3, 3, 3]), (64, 64, [3, 3, 3]), (96, 96, [3, 3, 3]),
               (128, 128, [3, 3, 3]), (160, 160, [3, 3, 3]), (192, 192, [3, 3, 3]), (192, 128, [1, 1, 1]),
-              (16, 48, [1, 3, 3]), (3, 5, [3, 3, 3]), (32, 80, [3, 3, 3]), (224, 224, [3, 3, 3]), (224, 3, [1, 1, 1]),
+              (16, 48, [1, 3, 3]), (3, 5, [3, 3, 3]), (32, 80, [3, 3, 3]), (224, 224, [3, 3, 3]), (224, 3, [1, 1, 1]), (40, 7, [3, 3, 3]),
               (256, 208, [1, 3, 3])]
 
 
