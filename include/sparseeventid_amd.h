@@ -80,6 +80,10 @@ int sei_batch_size(sei_metadata_t *m, int32_t *batch_size);
  * backward passes that follow synchronise nothing.  May run on the caller's main stream at the top of the forward pass, or
  * on a side stream ahead of it.  Fails like the lazy path would if a level of `like` does not exist for this batch. */
 int sei_metadata_prebuild_like(sei_metadata_t *m, sei_metadata_t *like, sei_stream_t stream);
+/* The same for a pass that will not differentiate (validation between training steps, inference): only the variants a
+ * FORWARD convolution of `like` fetched -- not the transposed rules of the strided layers (dX) nor the weight-gradient
+ * kernel's own variants. */
+int sei_metadata_prebuild_forward_like(sei_metadata_t *m, sei_metadata_t *like, sei_stream_t stream);
 
 /* ---- rulebooks (SCN `getSubmanifoldRuleBook` / `getRuleBook`) ---------------------------- */
 /* Cached in the metadata per (spatial, filter).  Synchronises `stream` on first build. */
@@ -135,8 +139,9 @@ int sei_set_backward_streams(int32_t mode);
 /* `stream` waits for everything sei_conv_backward queued on its side stream so far (no-op if nothing was) */
 int sei_backward_join(sei_stream_t stream);
 /* Test / sweep hook: pins the forward / dX kernel family for every later convolution of the process
- * (0 = the plan picks (default), 1 = workgroup-tile kernel, 2 = wave-private kernel, 3 = row-band kernel).  The
- * families produce bit-identical results (same per-row summation order); tests/test_gpu_kernels_agree.py asserts it. */
+ * (0 = the plan picks (default), 1 = workgroup-tile kernel, 2 = wave-private kernel, 3 = row-band kernel: experiment
+ * builds only, the shipped library returns an error for it).  The families produce bit-identical results (same per-row
+ * summation order); tests/test_gpu_kernels_agree.py asserts it. */
 int sei_debug_force_conv_kernel(int32_t kind);
 /* Same for the dW kernel: 0 = the library's choice, 1 = register-operand kernel, 2 = LDS-operand (ring) kernel -- an
  * experiment that measured slower and is compiled only with EXTRA=-DSEI_EXPERIMENTS (the shipped library returns an

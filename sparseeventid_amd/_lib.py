@@ -33,6 +33,7 @@ _SIGNATURES = {
     "sei_conv_rulebook": (ctypes.c_int, [vp, c_i32p, c_i32p, c_i32p, vp, ctypes.POINTER(vp), c_i32p]),
     "sei_rulebook_info": (ctypes.c_int, [vp, c_i64p]),
     "sei_metadata_prebuild_like": (ctypes.c_int, [vp, vp, vp]),
+    "sei_metadata_prebuild_forward_like": (ctypes.c_int, [vp, vp, vp]),
     "sei_rulebook_build": (ctypes.c_int, [vp, ctypes.c_int32, vp]),
     "sei_rulebook_export": (ctypes.c_int, [vp, c_i64p, vp, vp, vp]),
     "sei_conv_forward": (ctypes.c_int, [vp, vp, vp, vp, vp, ctypes.c_int32, ctypes.c_int32, vp]),

@@ -27,7 +27,10 @@ typedef std::pair<int, hipStream_t> PoolKey;
 // any stream -- is done.
 struct Fence {
     std::vector<hipEvent_t> events;
-    int blocks = 0;  // quarantined blocks still waiting on this fence
+    // references: one per quarantined block still waiting on this fence, plus ONE held by the owner between
+    // pool_fence_begin and pool_fence_end -- a concurrent pool_alloc that reaps the fence's first blocks (their events may
+    // already have completed) must not delete it under the owner, who is still adding blocks
+    int refs = 1;
 };
 struct Quarantined {
     void *p;
@@ -57,6 +60,12 @@ bool fence_done_locked(Fence *f) {
     return true;
 }
 
+void fence_unref_locked(Fence *f) {
+    if (--f->refs > 0) return;
+    for (hipEvent_t ev : f->events) g_pool.spare_events.push_back(ev);
+    delete f;
+}
+
 // quarantined blocks whose fence has completed go back to their free lists
 void reap_quarantine_locked() {
     size_t keep = 0;
@@ -64,7 +73,7 @@ void reap_quarantine_locked() {
         Quarantined q = g_pool.quarantine[i];
         if (fence_done_locked(q.fence)) {
             g_pool.free_blocks[PoolKey(q.b.device, q.b.stream)].emplace(q.b.size, q.p);
-            if (--q.fence->blocks == 0) delete q.fence;
+            fence_unref_locked(q.fence);
         } else {
             g_pool.quarantine[keep++] = q;
         }
@@ -187,7 +196,7 @@ void pool_free_fenced(void *p, PoolFence fence) {
     auto it = g_pool.live.find(p);
     if (it == g_pool.live.end()) return;
     g_pool.quarantine.push_back(Quarantined{p, it->second, f});
-    f->blocks++;
+    f->refs++;
     g_pool.in_use -= it->second.size;
     g_pool.live.erase(it);
 }
@@ -195,10 +204,7 @@ void pool_free_fenced(void *p, PoolFence fence) {
 void pool_fence_end(PoolFence fence) {
     Fence *f = (Fence *)fence;
     std::lock_guard<std::mutex> lk(g_pool.mu);
-    if (f->blocks == 0) {
-        for (hipEvent_t ev : f->events) g_pool.spare_events.push_back(ev);
-        delete f;
-    }
+    fence_unref_locked(f);  // the owner's reference; the last quarantined block deletes the fence otherwise
 }
 
 static std::atomic<long long> g_sync_count{0};
@@ -483,13 +489,13 @@ int sei_conv_rulebook(sei_metadata_t *m, const int32_t spatial_in[3], const int3
     return 0;
 }
 
-int sei_metadata_prebuild_like(sei_metadata_t *m, sei_metadata_t *like, sei_stream_t stream) {
+static int prebuild_like_impl(sei_metadata_t *m, sei_metadata_t *like, bool forward_only, sei_stream_t stream) {
     if (!m || !like) SEI_FAIL("sei_metadata_prebuild_like: null argument");
     if (m == like) return 0;
     struct Item {
         bool subm;
         int32_t sp[3], size[3], stride[3];
-        bool fwd[SEI_NVARIANT], bwd[SEI_NVARIANT];
+        bool fwd[SEI_NVARIANT], bwd[SEI_NVARIANT], fuse[SEI_NVARIANT];
     };
     std::vector<Item> items;
     {
@@ -499,7 +505,9 @@ int sei_metadata_prebuild_like(sei_metadata_t *m, sei_metadata_t *like, sei_stre
             Item it;
             it.subm = rb->submanifold;
             for (int d = 0; d < 3; d++) { it.sp[d] = rb->spatial_in[d]; it.size[d] = rb->size[d]; it.stride[d] = rb->stride[d]; }
-            for (int v = 0; v < SEI_NVARIANT; v++) { it.fwd[v] = rb->fwd[v].built; it.bwd[v] = rb->bwd[v].built; }
+            for (int v = 0; v < SEI_NVARIANT; v++) {
+                it.fwd[v] = rb->fwd[v].built; it.bwd[v] = rb->bwd[v].built; it.fuse[v] = rb->fwd[v].fwd_use;
+            }
             items.push_back(it);
         }
     }
@@ -513,11 +521,22 @@ int sei_metadata_prebuild_like(sei_metadata_t *m, sei_metadata_t *like, sei_stre
         if (it.subm) SEI_TRY(sei_subm_rulebook(m, it.sp, it.size, stream, &rb));
         else SEI_TRY(sei_conv_rulebook(m, it.sp, it.size, it.stride, stream, &rb, spo));
         for (int v = 0; v < SEI_NVARIANT; v++) {
-            if (it.fwd[v]) want.push_back(TiledRequest{rb, false, 64 * (v + 1)});
-            if (it.bwd[v] && !it.subm) want.push_back(TiledRequest{rb, true, 64 * (v + 1)});
+            // forward_only: the variants a FORWARD convolution of the template fetched -- not the transposed rules of the
+            // strided layers (dX) nor dW's 256-row variants: an evaluation pass between training steps builds nothing it
+            // will not walk
+            if (it.fwd[v] && (!forward_only || it.fuse[v])) want.push_back(TiledRequest{rb, false, 64 * (v + 1), it.fuse[v]});
+            if (it.bwd[v] && !it.subm && !forward_only) want.push_back(TiledRequest{rb, true, 64 * (v + 1), false});
         }
     }
     return build_tiled_batch(want, (hipStream_t)stream);
+}
+
+int sei_metadata_prebuild_like(sei_metadata_t *m, sei_metadata_t *like, sei_stream_t stream) {
+    return prebuild_like_impl(m, like, false, stream);
+}
+
+int sei_metadata_prebuild_forward_like(sei_metadata_t *m, sei_metadata_t *like, sei_stream_t stream) {
+    return prebuild_like_impl(m, like, true, stream);
 }
 
 int sei_rulebook_info(const sei_rulebook_t *rb_c, int64_t info[8]) {
@@ -577,7 +596,7 @@ static int conv_forward_impl(sei_rulebook_t *rb, const float *X, const float *W,
     const TiledRules *t;
     const int64_t n_dst = rb->lout ? rb->lout->n : 0;
     const ConvPlan p = plan_conv(nIn, nOut, rulebook_K(rb), n_dst);
-    SEI_TRY(get_tiled(rb, false, p.tile_rows, &t, st));
+    SEI_TRY(get_tiled(rb, false, p.tile_rows, &t, st, true));
     double *stats = nullptr;
     if (stats_out) {
         const int64_t parts = conv_stats_parts(p, *t);
@@ -643,7 +662,7 @@ int sei_conv_bn_inference(sei_rulebook_t *rb, const float *X, const float *W, co
     if (n == 0) return 0;
     const TiledRules *t;
     const ConvPlan p = plan_conv(nIn, nOut, rulebook_K(rb), n);
-    SEI_TRY(get_tiled(rb, false, p.tile_rows, &t, st));
+    SEI_TRY(get_tiled(rb, false, p.tile_rows, &t, st, true));
     float *ms;   // [mean | invstd], 16-byte aligned for the epilogue's float4 loads
     const int Cp = (nOut + 3) & ~3;
     SEI_TRY(pool_alloc_t(&ms, 2 * (size_t)Cp, st));
@@ -739,6 +758,7 @@ namespace {
 struct SideStream {
     hipStream_t s = nullptr;
     hipEvent_t e_in = nullptr, e_done = nullptr;
+    bool pending = false;   // mode 2: work queued since the last sei_backward_join
 };
 std::mutex g_side_mu;
 std::map<std::pair<int, hipStream_t>, SideStream> g_side;
@@ -772,15 +792,18 @@ int sei_backward_join(sei_stream_t stream) {
     hipStream_t st = (hipStream_t)stream;
     int dev = 0;
     SEI_HIP(hipGetDevice(&dev));
-    SideStream ss;
-    {
-        std::lock_guard<std::mutex> lk(g_side_mu);
-        auto it = g_side.find(std::make_pair(dev, st));
-        if (it == g_side.end() || !it->second.s) return 0;   // nothing was ever forked from this stream
-        ss = it->second;
+    // EVERY side stream of the device with un-joined work is joined into `stream`, not only the one paired with it: a join
+    // issued under another current stream than the one the backward kernels ran on (a caller that switched streams
+    // between backward() and the optimizer) would otherwise find no pair, do nothing, and let the optimizer read dW
+    // buffers the side stream has not written yet
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    for (auto &kv : g_side) {
+        SideStream &ss = kv.second;
+        if (kv.first.first != dev || !ss.s || !ss.pending) continue;
+        SEI_HIP(hipEventRecord(ss.e_done, ss.s));
+        SEI_HIP(hipStreamWaitEvent(st, ss.e_done, 0));
+        ss.pending = false;
     }
-    SEI_HIP(hipEventRecord(ss.e_done, ss.s));
-    SEI_HIP(hipStreamWaitEvent(st, ss.e_done, 0));
     return 0;
 }
 
@@ -795,6 +818,9 @@ int sei_debug_force_dw_kernel(int32_t kind) {
 
 int sei_debug_force_conv_kernel(int32_t kind) {
     if (kind < CONV_KERNEL_AUTO || kind > CONV_KERNEL_BAND) SEI_FAIL("sei_debug_force_conv_kernel: kind must be 0..3");
+#ifndef SEI_EXPERIMENTS
+    if (kind == CONV_KERNEL_BAND) SEI_FAIL("sei_debug_force_conv_kernel: the row-band kernels exist only in experiment builds (make EXTRA=-DSEI_EXPERIMENTS)");
+#endif
     g_force_kernel.store(kind);
     return 0;
 }
@@ -833,6 +859,11 @@ int sei_conv_backward(sei_rulebook_t *rb, const float *X, const float *dY, const
     if (g_bwd_streams.load(std::memory_order_relaxed) != 2) {   // mode 2: the caller joins (sei_backward_join)
         SEI_HIP(hipEventRecord(ss.e_done, ss.s));
         SEI_HIP(hipStreamWaitEvent(st, ss.e_done, 0));
+    } else {
+        int dev = 0;
+        SEI_HIP(hipGetDevice(&dev));
+        std::lock_guard<std::mutex> lk(g_side_mu);
+        g_side[std::make_pair(dev, st)].pending = true;
     }
     return rc1 ? rc1 : rc2;
 }

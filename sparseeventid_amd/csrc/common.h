@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <condition_variable>
 #include <map>
 #include <mutex>
 #include <string>
@@ -178,6 +179,8 @@ struct TiledRules {
     int32_t *sub_src = nullptr;         // [n_sub*16] src row or -1
     uint8_t *sub_dst = nullptr;         // [n_sub*16] dst row local to tile
     bool built = false;
+    bool fwd_use = false;               // fetched by a FORWARD convolution (sei_metadata_prebuild_forward_like builds only those)
+    bool building = false;              // begun by build_tiled_batch, not finished yet (rb->mu is released in between)
 };
 void free_tiled(TiledRules &t);
 
@@ -200,6 +203,7 @@ struct sei_rulebook {
     int32_t spatial_in[3], spatial_out[3], size[3], stride[3];
     sei::Level *lin = nullptr, *lout = nullptr;
     std::mutex mu;
+    std::condition_variable cv;         // signalled when a variant leaves the `building` state
 };
 
 struct sei_metadata {
@@ -233,7 +237,9 @@ int larcv_compact(const float *in, int B, int P, int M, int D, int32_t *coords, 
 // rulebook.hip
 inline int variant_of(int tile_rows) { return tile_rows / 64 - 1; }
 // returns the (lazily built) tiled rules of the rulebook: transposed=false -> fwd, true -> bwd
-int get_tiled(sei_rulebook *rb, bool transposed, int tile_rows, const TiledRules **out, hipStream_t st);
+// forward_use: the caller is a forward convolution (marks the variant for forward-only prebuilds)
+int get_tiled(sei_rulebook *rb, bool transposed, int tile_rows, const TiledRules **out, hipStream_t st,
+              bool forward_use = false);
 // any already-built variant (the smallest tile size first), building the 128-row one if none exists
 int get_any_tiled(sei_rulebook *rb, bool transposed, const TiledRules **out, hipStream_t st);
 // builds every listed variant that does not exist yet with ONE stream synchronisation for all of them
@@ -241,6 +247,7 @@ struct TiledRequest {
     sei_rulebook *rb;
     bool transposed;
     int tile_rows;
+    bool forward_use = false;   // carried over from the template's variant
 };
 int build_tiled_batch(const std::vector<TiledRequest> &want, hipStream_t st);
 int build_strided_level(sei_metadata *m, Level *lin, const int32_t size[3], const int32_t stride[3], sei_rulebook *rb,

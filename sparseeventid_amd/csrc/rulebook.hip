@@ -332,8 +332,9 @@ static void pending_abort(PendingTiled *pd) {
 static int tiled_begin_locked(sei_rulebook *rb, bool transposed, int tile_rows, PendingTiled *pd, bool *needed, hipStream_t st) {
     if (rb->submanifold) transposed = false;
     TiledRules &t = (transposed ? rb->bwd : rb->fwd)[variant_of(tile_rows)];
-    *needed = !t.built;
-    if (t.built) return 0;
+    // a variant another caller has begun (build_tiled_batch releases rb->mu between its halves) is not begun again
+    *needed = !t.built && !t.building;
+    if (!*needed) return 0;
     pd->dest = &t;
     int K = rb->size[0] * rb->size[1] * rb->size[2];
     ProbeGeom g{rb->submanifold ? 0 : 1, rb->size[0], rb->size[1], rb->size[2], rb->stride[0], rb->stride[1],
@@ -346,19 +347,26 @@ static int tiled_begin_locked(sei_rulebook *rb, bool transposed, int tile_rows, 
             dn = rb->donor->nbr_fwd;  // stays valid: rulebooks of one metadata are destroyed together
             ds = rb->donor->size;
         }
-        return build_tiled_begin(rb->lout->coords, rb->lout->n, rb->lin->n, rb->lin->ht, K, g, tile_rows, pd, &rb->nbr_fwd, st, dn, ds);
+        const int rc = build_tiled_begin(rb->lout->coords, rb->lout->n, rb->lin->n, rb->lin->ht, K, g, tile_rows, pd, &rb->nbr_fwd, st, dn, ds);
+        t.building = rc == 0;
+        return rc;
     }
     // dst = input sites probing the output-level hash
     g.mode = 2;
     g.s0 = rb->lout->spatial[0]; g.s1 = rb->lout->spatial[1]; g.s2 = rb->lout->spatial[2];
-    return build_tiled_begin(rb->lin->coords, rb->lin->n, rb->lout->n, rb->lout->ht, K, g, tile_rows, pd, &rb->nbr_bwd, st);
+    const int rc = build_tiled_begin(rb->lin->coords, rb->lin->n, rb->lout->n, rb->lout->ht, K, g, tile_rows, pd, &rb->nbr_bwd, st);
+    t.building = rc == 0;
+    return rc;
 }
 
-int get_tiled(sei_rulebook *rb, bool transposed, int tile_rows, const TiledRules **out, hipStream_t st) {
+int get_tiled(sei_rulebook *rb, bool transposed, int tile_rows, const TiledRules **out, hipStream_t st, bool forward_use) {
     if (tile_rows < 64 || tile_rows > 256 || tile_rows % 64) SEI_FAIL("rulebook: tile_rows must be 64, 128, 192 or 256");
-    std::lock_guard<std::mutex> lk(rb->mu);
+    std::unique_lock<std::mutex> lk(rb->mu);
     if (rb->submanifold) transposed = false;
     TiledRules &t = (transposed ? rb->bwd : rb->fwd)[variant_of(tile_rows)];
+    // a batch build of another thread (prefetch) holds this variant between its two halves: wait for it instead of
+    // starting a second build that would write the same slot
+    rb->cv.wait(lk, [&] { return !t.building; });
     if (!t.built) {
         PendingTiled pd;
         bool needed = false;
@@ -370,9 +378,11 @@ int get_tiled(sei_rulebook *rb, bool transposed, int tile_rows, const TiledRules
         if (!rc) rc = build_tiled_finish(&pd, st);
         if (rc) {
             pending_abort(&pd);
+            t.building = false;
             return rc;
         }
     }
+    if (forward_use) t.fwd_use = true;
     *out = &t;
     return 0;
 }
@@ -390,7 +400,7 @@ int build_tiled_batch(const std::vector<TiledRequest> &want, hipStream_t st) {
         rc = tiled_begin_locked(want[i].rb, want[i].transposed, want[i].tile_rows, &pend[i], &needed, st);
         live[i] = needed ? 1 : 0;
         any = any || (needed && !pend[i].empty);
-        if (rc && needed) { pending_abort(&pend[i]); live[i] = 0; }
+        if (rc && needed) { pending_abort(&pend[i]); live[i] = 0; }   // begin failed: `building` was never set
     }
     if (!rc && any && sync_stream(st) != hipSuccess) {
         set_error("rulebook: hipStreamSynchronize failed");
@@ -399,8 +409,17 @@ int build_tiled_batch(const std::vector<TiledRequest> &want, hipStream_t st) {
     for (size_t i = 0; i < want.size(); i++) {
         if (!live[i]) continue;
         std::lock_guard<std::mutex> lk(want[i].rb->mu);
-        if (!rc) rc = build_tiled_finish(&pend[i], st);
-        else pending_abort(&pend[i]);
+        bool done = false;
+        if (!rc) {
+            rc = build_tiled_finish(&pend[i], st);
+            done = rc == 0;
+            if (done && want[i].forward_use) pend[i].dest->fwd_use = true;
+        }
+        if (!done) {  // this item's finish failed, or an earlier item did: release what its two halves hold
+            pending_abort(&pend[i]);
+            pend[i].dest->building = false;
+        }
+        want[i].rb->cv.notify_all();
     }
     return rc;
 }

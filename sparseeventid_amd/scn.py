@@ -129,13 +129,16 @@ class Metadata:
     def handle(self):
         return self._h
 
-    def prebuild_like(self, other):
+    def prebuild_like(self, other, forward_only=False):
         """Build, for THIS batch, every rulebook (and tiled variant) the metadata of an earlier batch holds
         (``sei_metadata_prebuild_like``) on the current stream.  A training loop calls it on a side stream for the next
-        batch while the current step computes; the forward pass then finds its rulebooks built."""
+        batch while the current step computes; the forward pass then finds its rulebooks built.  ``forward_only``: only
+        the variants a forward convolution of ``other`` walked (``sei_metadata_prebuild_forward_like``) -- a pass that
+        will not differentiate needs neither the transposed rules nor dW's variants."""
         if other is None or other is self or other._h is None:
             return
-        check(lib().sei_metadata_prebuild_like(self._h, other._h, _stream()))
+        fn = lib().sei_metadata_prebuild_forward_like if forward_only else lib().sei_metadata_prebuild_like
+        check(fn(self._h, other._h, _stream()))
 
     def rows(self, spatial):
         n = ctypes.c_int64()

@@ -171,13 +171,16 @@ class Trainer:
             image = layer(image)     # Encoder.forward / ResNet.forward pass a prepared tensor through
             if self.batch_rulebooks and self._template is not None and image.features.is_cuda:
                 # every rulebook (forward AND backward variants) the previous batch needed, built now with ONE count
-                # read-back for all of them instead of one per variant spread over the forward and backward passes
+                # read-back for all of them instead of one per variant spread over the forward and backward passes;
+                # a pass that will not differentiate (eval_step, validation under no_grad) builds the forward variants only
                 try:
-                    image.metadata.prebuild_like(self._template)
+                    image.metadata.prebuild_like(self._template, forward_only=not torch.is_grad_enabled())
                 except RuntimeError as e:
                     if "no level with this spatial size" not in str(e) and "smaller than filter" not in str(e):
                         raise
-        self._template = image.metadata
+        # the template lists what a TRAINING step walks: a no-grad pass (forward variants only) does not replace it
+        if torch.is_grad_enabled() or self._template is None:
+            self._template = image.metadata
         if self.fused_head:
             return self.head.forward_pooled(self.encoder.forward_pooled(image))
         return self.head(self.encoder(image))

@@ -1,5 +1,5 @@
-"""GPU: the three forward / dX kernel families -- workgroup-tile (conv_fwd.hip), wave-private (conv_wave.hip) and row-band
-(conv_band.hip: row-band ownership + LDS weight ring filled by a loader wave) -- keep the SAME per-row summation order
+"""GPU: the forward / dX kernel families -- workgroup-tile (conv_fwd.hip), wave-private (conv_wave.hip) and, in experiment
+builds only, row-band (conv_band.hip: row-band ownership + LDS weight ring filled by a loader wave) -- keep the SAME per-row summation order
 (offsets ascending; inside an offset one MFMA chain over the input planes, then tile += partial), so their results are
 bit-identical: forward, dX, dX with the skip gradient folded in, and the BatchNorm statistics of the epilogue.  The
 row-band kernel's bounded poll loops must never run out (sei_debug_band_timeouts)."""
@@ -9,10 +9,10 @@ import numpy as np
 import pytest
 import torch
 
+from tests.conftest import conv_families
 from tests.util import blob_cloud
 
 pytestmark = pytest.mark.gpu
-FAMILIES = ("tile", "wave", "band")
 
 
 def _timeouts(reset=False):
@@ -47,6 +47,7 @@ def test_kernel_families_bit_identical(ci, co, filt, rows, force_conv_kernel):
     with torch.no_grad():
         conv.bias.normal_()
     res = {}
+    FAMILIES = conv_families()
     for fam in FAMILIES:
         force_conv_kernel(fam)
         xx = x.clone().requires_grad_(True)
@@ -75,6 +76,7 @@ def test_fused_residual_block_bit_identical_across_families(force_conv_kernel):
     x = torch.randn(n, C, device="cuda")
     gy = torch.randn(n, C, device="cuda")
     res = {}
+    FAMILIES = conv_families()
     for fam in FAMILIES:
         force_conv_kernel(fam)
         sd = {k: v.clone() for k, v in blk.state_dict().items()}
@@ -102,6 +104,9 @@ def test_band_kernel_strided_and_transposed_rules(force_conv_kernel):
     x = torch.randn(n, 96, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
     conv = scn.Convolution(3, 96, 128, 2, 2, False).cuda()
     res = {}
+    FAMILIES = conv_families()
+    if "band" not in FAMILIES:
+        pytest.skip("library built without -DSEI_EXPERIMENTS: no row-band kernels")
     for fam in FAMILIES:
         force_conv_kernel(fam)
         xx = x.clone().requires_grad_(True)

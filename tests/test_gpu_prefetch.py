@@ -109,7 +109,7 @@ def test_training_with_prefetch_is_bit_identical_to_lazy_training(overlapped):
 @pytest.mark.parametrize("mode", [1, 2])
 def test_two_stream_backward_is_bit_identical(mode):
     """scn.set_backward_streams: dW of every layer on the library's side stream next to dX (sei_conv_backward), joined per
-    layer (1) or once per backward pass (2: Trainer.train_step joins; operands pinned with record_stream) -- same kernels,
+    layer (1) or once per backward pass (2: Trainer.train_step joins; operands held by the python layer until the join, not record_stream'ed) -- same kernels,
     same results; also together with the overlapped prefetch."""
     import sparseeventid_amd.scn as scn
     base, over = _trainer(), _trainer()
@@ -223,3 +223,72 @@ def test_batched_rulebook_build_needs_one_readback_and_changes_nothing():
     assert counts["batched"][0] == counts["lazy"][0]              # first step: nothing to copy the list from
     assert all(c == 1 + levels + 1 for c in counts["batched"][1:]), counts
     assert all(c > 1 + levels + 1 for c in counts["lazy"]), counts
+
+
+def test_forward_only_prebuild_skips_the_backward_variants():
+    """sei_metadata_prebuild_forward_like builds what a forward pass of the template walked and nothing else: a backward
+    pass behind it still finds its variants missing (it builds them lazily: stream synchronisations), one behind the
+    full prebuild finds everything built (none).  Results are the same either way."""
+    import sparseeventid_amd.scn as scn
+    sp = [24, 20, 28]
+    ca, fa = blob_cloud(5, 2, sp, 400, 1)
+    cb, fb = blob_cloud(6, 2, sp, 520, 1)
+    layer = scn.InputLayer(3, sp)
+    torch.manual_seed(5)
+    sub = scn.SubmanifoldConvolution(3, 16, 32, 3, False).cuda()
+    down = scn.Convolution(3, 32, 48, 2, 2, False).cuda()
+
+    def run(t, x):
+        t.features = x.clone().requires_grad_(True)
+        y = down(sub(t))
+        y.features.square().sum().backward()
+        return y.features.detach().clone(), t.features.grad.clone(), sub.weight.grad.clone(), down.weight.grad.clone()
+
+    ta = layer((torch.from_numpy(ca), torch.from_numpy(fa).cuda(), 2))
+    run(ta, torch.randn(ta.features.shape[0], 16, device="cuda"))       # the template: forward + backward variants
+    res, syncs = {}, {}
+    xb = None
+    for name, fwd_only in (("full", False), ("forward", True)):
+        tb = layer((torch.from_numpy(cb), torch.from_numpy(fb).cuda(), 2))
+        if xb is None:
+            xb = torch.randn(tb.features.shape[0], 16, device="cuda")
+        tb.metadata.prebuild_like(ta.metadata, forward_only=fwd_only)
+        sub.weight.grad = None; down.weight.grad = None
+        torch.cuda.synchronize()
+        _sync_count(reset=True)
+        with torch.no_grad():
+            down(sub(scn.SparseConvNetTensor(xb, tb.metadata, tb.spatial_size)))
+        torch.cuda.synchronize()
+        assert _sync_count() == 0, name          # the forward pass finds its variants built in both cases
+        res[name] = run(tb, xb)
+        torch.cuda.synchronize()
+        syncs[name] = _sync_count()
+    assert syncs["full"] == 0 and syncs["forward"] > 0, syncs
+    for a, b in zip(res["full"], res["forward"]):
+        assert torch.equal(a, b)
+
+
+def test_eval_step_between_training_steps_keeps_the_training_template():
+    """Trainer.eval_step (no_grad) prebuilds the forward variants only and does not replace the template of the training
+    steps: the step after it still needs ONE read-back for its rulebooks; logits equal the lazy path's."""
+    lazy, batched = _trainer(), _trainer()
+    lazy.batch_rulebooks = False
+    data = _batches(lazy)
+    torch.manual_seed(31)
+    out = {}
+    for name, tr in (("lazy", lazy), ("batched", batched)):
+        tr.train_step(*data[0])
+        tr.train_step(*data[1])
+        torch.cuda.synchronize()
+        _sync_count(reset=True)
+        logits = tr.eval_step(data[2][0])
+        torch.cuda.synchronize()
+        n_eval = _sync_count(reset=True)
+        tr.train_step(*data[0])
+        torch.cuda.synchronize()
+        out[name] = (logits, n_eval, _sync_count())
+    for k in out["lazy"][0]:
+        assert torch.equal(out["lazy"][0][k], out["batched"][0][k]), k
+    levels = 2
+    assert out["batched"][1] == 1 + levels + 1 and out["batched"][2] == 1 + levels + 1, out["batched"][1:]
+    assert torch.equal(lazy.arena.flat, batched.arena.flat)
