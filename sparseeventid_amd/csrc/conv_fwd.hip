@@ -43,6 +43,59 @@ __device__ unsigned long long g_stamps[16];
 #define STAMP_FLUSH
 #endif
 
+// Diagnostic build only (make EXTRA="-DSEI_EXPERIMENTS -DSEI_TRACE"; tools/trace_tile.py): the TIMELINE of one compute
+// unit.  The first workgroup of a launch claims its CU; every workgroup that runs on that CU afterwards takes a slot and
+// each of its waves writes, per phase, the s_memtime at: barrier exit, loads issued, MFMA block done, end of phase (after
+// the write-back at the end of an offset), with the number of sub-chunks it held in the low bits.  Answers what the
+// aggregated stamps cannot: which waves of which workgroups want one SIMD's matrix pipe at the same time, and what the
+// last wave at each barrier was doing.  The product build compiles none of it.
+#ifdef SEI_TRACE
+constexpr int TRACE_SLOTS = 96, TRACE_WAVES = 8, TRACE_EV = 512;
+struct TraceBuf {
+    int cu_key;                 // -1 until claimed: (xcc_id << 16) | (hw_id & 0xFF00)
+    int n_slots;
+    int hw[TRACE_SLOTS][TRACE_WAVES];       // raw HW_ID of each wave
+    int nev[TRACE_SLOTS][TRACE_WAVES];
+    int vid[TRACE_SLOTS];
+    unsigned long long t0[TRACE_SLOTS], t1[TRACE_SLOTS];   // workgroup start / end (wave 0)
+    unsigned long long ev[TRACE_SLOTS][TRACE_WAVES][TRACE_EV];
+};
+__device__ TraceBuf g_trace;
+#define TRACE_DECL                                                                                      \
+    int &tr_slot_s = seg[K + 1];   /* one word behind the segment table (fwd_lds reserves it in this build) */ \
+    int tr_n = 0;                                                                                       \
+    {                                                                                                   \
+        const int hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xF; \
+        const int key = (xcc << 16) | (hw & 0xFF00);                                                    \
+        if (threadIdx.x == 0) {                                                                         \
+            int prev = atomicCAS(&g_trace.cu_key, -1, key);                                             \
+            int sl = -1;                                                                                \
+            if (prev == -1 || prev == key) sl = atomicAdd(&g_trace.n_slots, 1);                         \
+            if (sl >= TRACE_SLOTS) sl = -1;                                                             \
+            tr_slot_s = sl;                                                                             \
+            if (sl >= 0) { g_trace.vid[sl] = vid; g_trace.t0[sl] = __builtin_amdgcn_s_memtime(); }      \
+        }                                                                                               \
+        __syncthreads();                                                                                \
+        if (tr_slot_s >= 0 && lane == 0 && wave < TRACE_WAVES) g_trace.hw[tr_slot_s][wave] = hw;        \
+    }                                                                                                   \
+    const int tr_slot = tr_slot_s
+#define TRACE(tag)                                                                                      \
+    do {                                                                                                \
+        if (tr_slot >= 0 && lane == 0 && wave < TRACE_WAVES && tr_n < TRACE_EV)                         \
+            g_trace.ev[tr_slot][wave][tr_n] = (__builtin_amdgcn_s_memtime() << 8) | (unsigned long long)(tag); \
+        tr_n++;                                                                                         \
+    } while (0)
+#define TRACE_END                                                                                       \
+    do {                                                                                                \
+        if (tr_slot >= 0 && lane == 0 && wave < TRACE_WAVES) g_trace.nev[tr_slot][wave] = tr_n < TRACE_EV ? tr_n : TRACE_EV; \
+        if (tr_slot >= 0 && threadIdx.x == 0) g_trace.t1[tr_slot] = __builtin_amdgcn_s_memtime();      \
+    } while (0)
+#else
+#define TRACE_DECL
+#define TRACE(tag)
+#define TRACE_END
+#endif
+
 // B operands of one input plane for the wave's NT column tiles.  The weight columns of every column
 // group are stored permuted (conv_permute_col) so that lane r16 finds the values of 4 (2, 1) column
 // tiles in ONE ds_read_b128 (b64, b32): position 64b + 4r + j holds column 64b + 16j + r.
@@ -101,6 +154,113 @@ __device__ __forceinline__ void compute_phase(const float *__restrict__ wb, cons
     }
 }
 
+// ---- software-pipelined form of the phase (SEI_PIPE; the default since round 4) -----------------------------------------
+// What the per-CU timeline of round 4 showed (tools/trace_tile.py, profiles/r04_trace_*): hipcc closes every pair of MFMA
+// steps of compute_phase with  s_waitcnt lgkmcnt(0)  -- it also waits for the B reads it has just issued for the NEXT step,
+// one full LDS latency with the matrix pipe idle every 12 MFMAs (a 48-MFMA block took 2200 ticks alone on its SIMD, not
+// 1536) -- and the phase's other work (weight-slice DMA, gathers: ~1000 ticks; tile write-back: ~1800 per offset) sits in
+// front of / behind the block instead of inside it.  Here the B operands are read by inline-asm ds_read with COUNTED waits
+// (LDS returns in order: after issuing the RPS reads of step st+1,  lgkmcnt(RPS)  means step st's have landed), the first
+// step's reads are issued right behind the barrier, and the caller's auxiliary work is issued between the steps.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t lds_off(const float *p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float *)p;
+}
+template <int OFF> __device__ __forceinline__ f32x4 dsr128(uint32_t a) {
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF));
+    return v;
+}
+template <int OFF> __device__ __forceinline__ f32x2 dsr64(uint32_t a) {
+    f32x2 v;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF));
+    return v;
+}
+template <int OFF> __device__ __forceinline__ float dsr32(uint32_t a) {
+    float v;
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF));
+    return v;
+}
+template <int N> __device__ __forceinline__ void lgkm_wait() {
+    static_assert(N >= 0 && N <= 15, "lgkmcnt is a 4-bit counter");
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+    // hipcc hoists register-only MFMAs past an inline-asm wait: nothing may cross
+    __builtin_amdgcn_sched_barrier(0);
+}
+// LDS read instructions of one step's B operands (load_b's b128 / b64 / b32 shapes)
+constexpr int b_reads(int nt) { return nt / 4 + ((nt % 4) >= 2 ? 1 : 0) + ((nt % 4) == 1 || (nt % 4) == 3 ? 1 : 0); }
+// a128 / a64 / a32: LDS byte address of the wave's step-0 weight row (+ 4 g rows) at lane offsets 16 r16 / 8 r16 / 4 r16
+template <int NT, int OFF>
+__device__ __forceinline__ void read_b(uint32_t a128, uint32_t a64, uint32_t a32, float (&b)[NT]) {
+    constexpr int B4 = NT / 4, REM = NT % 4;
+#pragma unroll
+    for (int q = 0; q < B4; q++) {
+        f32x4 v;
+        if (q == 0) v = dsr128<OFF>(a128);
+        else if (q == 1) v = dsr128<OFF + 256>(a128);
+        else if (q == 2) v = dsr128<OFF + 512>(a128);
+        else v = dsr128<OFF + 768>(a128);
+        b[4 * q + 0] = v[0]; b[4 * q + 1] = v[1]; b[4 * q + 2] = v[2]; b[4 * q + 3] = v[3];
+    }
+    if (REM >= 2) {
+        const f32x2 v = dsr64<OFF + 256 * B4>(a64);
+        b[4 * B4 + 0] = v[0]; b[4 * B4 + 1] = v[1];
+    }
+    if (REM == 1) b[4 * B4] = dsr32<OFF + 256 * B4>(a32);
+    if (REM == 3) b[4 * B4 + 2] = dsr32<OFF + 256 * B4 + 128>(a32);
+}
+
+template <int ST, int STEPS, int NT, int SLJ, int MS, int MAXS, int COUT, class Aux>
+struct PipeStep {
+    static __device__ __forceinline__ void run(uint32_t a128, uint32_t a64, uint32_t a32, const float4 (&a)[MAXS][SLJ],
+                                               f32x4 (&acc)[MAXS][NT], float (&b)[2][NT], Aux &aux) {
+        constexpr int jj = ST >> 2, e = ST & 3;
+        constexpr int RPS = b_reads(NT);
+        if (ST + 1 < STEPS) {
+            constexpr int jn = (ST + 1) >> 2, en = (ST + 1) & 3;
+            read_b<NT, (16 * jn + en) * COUT * 4>(a128, a64, a32, b[(ST + 1) & 1]);
+        }
+        aux(ST);                       // the caller's slot: weight-slice DMA / a gather / tile reads of the write-back
+        if (ST + 1 < STEPS) lgkm_wait<RPS>(); else lgkm_wait<0>();
+#pragma unroll
+        for (int m = 0; m < MS; m++) {
+            const float av = e == 0 ? a[m][jj].x : e == 1 ? a[m][jj].y : e == 2 ? a[m][jj].z : a[m][jj].w;
+#pragma unroll
+            for (int n = 0; n < NT; n++) acc[m][n] = mfma16(av, b[ST & 1][n], acc[m][n]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        PipeStep<ST + 1, STEPS, NT, SLJ, MS, MAXS, COUT, Aux>::run(a128, a64, a32, a, acc, b, aux);
+    }
+};
+template <int STEPS, int NT, int SLJ, int MS, int MAXS, int COUT, class Aux>
+struct PipeStep<STEPS, STEPS, NT, SLJ, MS, MAXS, COUT, Aux> {
+    static __device__ __forceinline__ void run(uint32_t, uint32_t, uint32_t, const float4 (&)[MAXS][SLJ], f32x4 (&)[MAXS][NT],
+                                               float (&)[2][NT], Aux &) {}
+};
+
+// one (k, slice) phase of a wave holding MS sub-chunks (MS = 0: none -- only the auxiliary slots run)
+template <int NT, int SLJ, int MS, int MAXS, int COUT, class Aux>
+__device__ __forceinline__ void pipe_phase(const float *__restrict__ wb, const float4 (&a)[MAXS][SLJ], f32x4 (&acc)[MAXS][NT],
+                                           int g, int r16, Aux &aux) {
+    constexpr int STEPS = 4 * SLJ;
+    if (MS == 0) {
+#pragma unroll
+        for (int st = 0; st < STEPS; st++) aux(st);
+        // An idle wave has nothing else to do than wait for what it has just issued (it would at the phase barrier), and
+        // the wait must be one the compiler SEES (a real S_WAITCNT: vmcnt(0), other counters untouched): hipcc lowers the
+        // dispatch on ms to  if (ms == 0) {..}  if (ms == 1) {..}  one behind the other, and without it its waitcnt pass takes
+        // this path's gathers as possibly pending where the busy path's MFMAs reuse their registers -- and puts a
+        // vmcnt(0), a full memory latency behind the weight DMA just issued, into the middle of the MFMA block.
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        return;
+    }
+    const uint32_t row0 = lds_off(wb + (4 * g) * COUT);
+    const uint32_t a128 = row0 + 16 * r16, a64 = row0 + 8 * r16, a32 = row0 + 4 * r16;
+    float b[2][NT];
+    read_b<NT, 0>(a128, a64, a32, b[0]);
+    PipeStep<0, STEPS, NT, SLJ, MS, MAXS, COUT, Aux>::run(a128, a64, a32, a, acc, b, aux);
+}
+
 template <int MAXS>
 struct RuleIdx {
     int src[MAXS];        // lane r16: src row of rule slot r16 (A operand row); RAW load, see valid()
@@ -155,6 +315,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : occ_for(MAXS, NT, SLJ))) vo
     int *seg = reinterpret_cast<int *>(wbuf + 2 * SL * COUT);
 
     STAMP_DECL;
+    TRACE_DECL;
     for (int i = threadIdx.x; i <= K; i += 64 * NW) seg[i] = tile_seg[(size_t)tile * (K + 1) + i];
     tile_init<TR, COUT, 64 * NW>(acc_tile, bias, init, (int64_t)tile * TR, n_dst, ldy, ycol0);
     __syncthreads();
@@ -199,6 +360,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : occ_for(MAXS, NT, SLJ))) vo
 #pragma unroll
             for (int jj = 0; jj < SLJ; jj++) {
                 a_c[m][jj] = load_a(X, ic.row(m), CIN, 16 * jj + 4 * g);
+#ifdef SEI_DEFER_SELECT
+                if (ic.row(m) < 0) a_c[m][jj] = make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
                 a_n[m][jj] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         int phase = 0;
@@ -226,6 +390,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : occ_for(MAXS, NT, SLJ))) vo
                 else
                     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" SEI_BARRIER_INSN ::: "memory");
                 STAMP(0);
+                TRACE(0);
                 if (s == 0) {
                     // the offset's products are summed from zero (see the write-back below)
 #pragma unroll
@@ -236,15 +401,60 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : occ_for(MAXS, NT, SLJ))) vo
                 STAMP(1);
                 // prefetch the next phase's weight slice and A fragments while this one computes
                 const bool same_k = s + 1 < NS;
-#ifndef SEI_ABL_NODMA
-                stage_slice<PIECES, NW>(W + ((size_t)(same_k ? k : kw) * CIN + (size_t)(same_k ? s + 1 : 0) * SL) * COUT,
-                                    wbuf + (size_t)((phase + 1) & 1) * SL * COUT, wave, lane);
-#endif
+                const float *wnext = W + ((size_t)(same_k ? k : kw) * CIN + (size_t)(same_k ? s + 1 : 0) * SL) * COUT;
+                float *wdst = wbuf + (size_t)((phase + 1) & 1) * SL * COUT;
                 const int aoff = (same_k ? (s + 1) * SL : 0) + 4 * g;
 #ifdef SEI_TILE_SKIP  // experiment: gather only the sub-chunks the wave owns in that phase
                 const int msn = same_k ? ic.ms : in1.ms;
 #else
                 const int msn = MAXS;
+#endif
+                const float *wb = wbuf + (size_t)(phase & 1) * SL * COUT + col0;
+#ifdef SEI_PIPE
+                // the phase's other work is issued from the slots BETWEEN the MFMA steps (pipe_phase): slot 0 the weight
+                // slice DMA, slots 1.. one gather each (whatever is left over in the last slot)
+                auto aux = [&](int st) {
+                    constexpr int STEPS = 4 * SLJ;
+#ifndef SEI_ABL_NODMA
+                    if (st == 0) stage_slice<PIECES, NW>(wnext, wdst, wave, lane);
+#endif
+#pragma unroll
+                    for (int m = 0; m < MAXS; m++)
+#pragma unroll
+                        for (int jj = 0; jj < SLJ; jj++) {
+                            const int p = m * SLJ + jj + 1;   // the slot of this gather
+                            if ((p == st || (st == STEPS - 1 && p > st)) && (m == 0 || m < msn))
+                                a_n[m][jj] = load_a(X, same_k ? ic.row(m) : in1.row(m), CIN, aoff + 16 * jj);
+                        }
+                };
+                STAMP(2);
+                TRACE(1);
+                {   // exclusive paths, and only the sub-chunk counts this instantiation can hold
+                    const int msu = __builtin_amdgcn_readfirstlane(ic.ms);
+                    if (msu == 0) pipe_phase<NT, SLJ, 0, MAXS, COUT>(wb, a_c, acc, g, r16, aux);
+                    else if (MAXS == 1 || msu == 1) pipe_phase<NT, SLJ, 1, MAXS, COUT>(wb, a_c, acc, g, r16, aux);
+                    else if (MAXS == 2 || msu == 2) pipe_phase<NT, SLJ, (MAXS >= 2 ? 2 : 1), MAXS, COUT>(wb, a_c, acc, g, r16, aux);
+                    else if (MAXS == 3 || msu == 3) pipe_phase<NT, SLJ, (MAXS >= 3 ? 3 : 1), MAXS, COUT>(wb, a_c, acc, g, r16, aux);
+                    else pipe_phase<NT, SLJ, (MAXS >= 4 ? 4 : 1), MAXS, COUT>(wb, a_c, acc, g, r16, aux);
+                }
+#else
+#ifndef SEI_ABL_NODMA
+#ifdef SEI_IDLE_DMA
+                {   // the waves without a sub-chunk in this phase load the next weight slice (all of them, if every wave is busy)
+                    const int nsub = __builtin_amdgcn_readfirstlane(seg[k + 1] - seg[k]);
+                    const int nbusy = (nsub < U ? nsub : U) * CS;
+                    if (nbusy >= NW) stage_slice<PIECES, NW>(wnext, wdst, wave, lane);
+                    else stage_slice_by<PIECES>(wnext, wdst, wave - nbusy, NW - nbusy, lane);
+                }
+#else
+                stage_slice<PIECES, NW>(wnext, wdst, wave, lane);
+#endif
+#endif
+#ifdef SEI_STAGGER
+                // the second half of the workgroup's waves (the SIMD partners of the first half) computes FIRST and gathers
+                // afterwards: partners then want the matrix pipe and the vector-memory path at different times
+                const bool late = NW == 8 && wave >= NW / 2;
+                if (!late)
 #endif
 #pragma unroll
                 for (int m = 0; m < MAXS; m++)
@@ -253,8 +463,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : occ_for(MAXS, NT, SLJ))) vo
                         for (int jj = 0; jj < SLJ; jj++)
                             a_n[m][jj] = load_a(X, same_k ? ic.row(m) : in1.row(m), CIN, aoff + 16 * jj);
                     }
-                const float *wb = wbuf + (size_t)(phase & 1) * SL * COUT + col0;
                 STAMP(2);
+                TRACE(1);
                 if (MAXS == 1) {
                     if (ic.ms == 1) compute_phase<NT, SLJ, 1, MAXS, COUT>(wb, a_c, acc, g, r16);
                 } else if (MAXS == 2) {
@@ -269,13 +479,35 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : occ_for(MAXS, NT, SLJ))) vo
                         default: break;
                     }
                 }
+#ifdef SEI_STAGGER
+                if (late) {
+#pragma unroll
+                    for (int m = 0; m < MAXS; m++)
+                        if (m == 0 || m < msn) {
+#pragma unroll
+                            for (int jj = 0; jj < SLJ; jj++)
+                                a_n[m][jj] = load_a(X, same_k ? ic.row(m) : in1.row(m), CIN, aoff + 16 * jj);
+                        }
+                }
+#endif
+#endif
                 STAMP(3);
+                TRACE(2 | (ic.ms << 2));
                 STAMP_ADD(8, 1);
                 STAMP_ADD(9, ic.ms * NT * 4 * SLJ);
 #pragma unroll
-                for (int m = 0; m < MAXS; m++)
+                for (int m = 0; m < MAXS; m++) {
+#ifdef SEI_DEFER_SELECT
+                    // padding slots feed zeros (conv_tile.h: load_a); applied HERE, when the gathered values are first
+                    // needed, not behind the load
+                    const bool pad = (same_k ? ic.row(m) : in1.row(m)) < 0;
+#pragma unroll
+                    for (int jj = 0; jj < SLJ; jj++) a_c[m][jj] = pad ? make_float4(0.f, 0.f, 0.f, 0.f) : a_n[m][jj];
+#else
 #pragma unroll
                     for (int jj = 0; jj < SLJ; jj++) a_c[m][jj] = a_n[m][jj];
+#endif
+                }
                 phase++;
                 STAMP(4);
             }
@@ -306,6 +538,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : occ_for(MAXS, NT, SLJ))) vo
                 }
             }
             STAMP(5);
+            TRACE(3);
             ic = in1;
             in1 = in2;
             k = k1;
@@ -322,6 +555,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : occ_for(MAXS, NT, SLJ))) vo
     STAMP(11);
     STAMP_ADD(7, 1);
     STAMP_FLUSH;
+    TRACE_END;
 }
 
 // Stem-type convolutions (tiny nIn, e.g. 1 -> 32 with 125 offsets): all of W sits in LDS, lane = output plane so that
@@ -477,7 +711,11 @@ __global__ void fill_bias_kernel(float *Y, int64_t n, int C, const float *bias) 
 }
 
 static size_t fwd_lds(int tile_rows, int nOut, int slj, int K) {
-    return ((size_t)tile_rows * (nOut + APAD) + 2 * 16 * slj * nOut) * sizeof(float) + (K + 1) * sizeof(int);
+    size_t b = ((size_t)tile_rows * (nOut + APAD) + 2 * 16 * slj * nOut) * sizeof(float) + (K + 1) * sizeof(int);
+#ifdef SEI_TRACE
+    b += 16;   // the trace slot of the workgroup
+#endif
+    return b;
 }
 
 #ifdef SEI_EXPERIMENTS
@@ -708,6 +946,22 @@ int conv_forward(const TiledRules &t, const float *X, const float *W, const floa
 }
 
 }  // namespace sei
+
+#ifdef SEI_TRACE
+extern "C" int sei_debug_trace(void *out, long long bytes, int reset) {
+    if (out && bytes > 0) {
+        if ((size_t)bytes > sizeof(sei::TraceBuf)) bytes = sizeof(sei::TraceBuf);
+        if (hipMemcpyFromSymbol(out, HIP_SYMBOL(sei::g_trace), (size_t)bytes) != hipSuccess) return 1;
+    }
+    if (reset) {
+        static sei::TraceBuf z;   // zero-initialised
+        z.cu_key = -1;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(sei::g_trace), &z, sizeof(int) * 2) != hipSuccess) return 1;
+    }
+    return 0;
+}
+extern "C" long long sei_debug_trace_bytes(void) { return (long long)sizeof(sei::TraceBuf); }
+#endif
 
 #ifdef SEI_STAMPS
 extern "C" int sei_debug_stamps(unsigned long long *out, int reset) {

@@ -274,9 +274,9 @@ def test_eval_step_between_training_steps_keeps_the_training_template():
     lazy, batched = _trainer(), _trainer()
     lazy.batch_rulebooks = False
     data = _batches(lazy)
-    torch.manual_seed(31)
     out = {}
     for name, tr in (("lazy", lazy), ("batched", batched)):
+        torch.manual_seed(31)
         tr.train_step(*data[0])
         tr.train_step(*data[1])
         torch.cuda.synchronize()
