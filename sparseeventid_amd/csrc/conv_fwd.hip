@@ -154,113 +154,6 @@ __device__ __forceinline__ void compute_phase(const float *__restrict__ wb, cons
     }
 }
 
-// ---- software-pipelined form of the phase (SEI_PIPE; the default since round 4) -----------------------------------------
-// What the per-CU timeline of round 4 showed (tools/trace_tile.py, profiles/r04_trace_*): hipcc closes every pair of MFMA
-// steps of compute_phase with  s_waitcnt lgkmcnt(0)  -- it also waits for the B reads it has just issued for the NEXT step,
-// one full LDS latency with the matrix pipe idle every 12 MFMAs (a 48-MFMA block took 2200 ticks alone on its SIMD, not
-// 1536) -- and the phase's other work (weight-slice DMA, gathers: ~1000 ticks; tile write-back: ~1800 per offset) sits in
-// front of / behind the block instead of inside it.  Here the B operands are read by inline-asm ds_read with COUNTED waits
-// (LDS returns in order: after issuing the RPS reads of step st+1,  lgkmcnt(RPS)  means step st's have landed), the first
-// step's reads are issued right behind the barrier, and the caller's auxiliary work is issued between the steps.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t lds_off(const float *p) {
-    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float *)p;
-}
-template <int OFF> __device__ __forceinline__ f32x4 dsr128(uint32_t a) {
-    f32x4 v;
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF));
-    return v;
-}
-template <int OFF> __device__ __forceinline__ f32x2 dsr64(uint32_t a) {
-    f32x2 v;
-    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF));
-    return v;
-}
-template <int OFF> __device__ __forceinline__ float dsr32(uint32_t a) {
-    float v;
-    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF));
-    return v;
-}
-template <int N> __device__ __forceinline__ void lgkm_wait() {
-    static_assert(N >= 0 && N <= 15, "lgkmcnt is a 4-bit counter");
-    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
-    // hipcc hoists register-only MFMAs past an inline-asm wait: nothing may cross
-    __builtin_amdgcn_sched_barrier(0);
-}
-// LDS read instructions of one step's B operands (load_b's b128 / b64 / b32 shapes)
-constexpr int b_reads(int nt) { return nt / 4 + ((nt % 4) >= 2 ? 1 : 0) + ((nt % 4) == 1 || (nt % 4) == 3 ? 1 : 0); }
-// a128 / a64 / a32: LDS byte address of the wave's step-0 weight row (+ 4 g rows) at lane offsets 16 r16 / 8 r16 / 4 r16
-template <int NT, int OFF>
-__device__ __forceinline__ void read_b(uint32_t a128, uint32_t a64, uint32_t a32, float (&b)[NT]) {
-    constexpr int B4 = NT / 4, REM = NT % 4;
-#pragma unroll
-    for (int q = 0; q < B4; q++) {
-        f32x4 v;
-        if (q == 0) v = dsr128<OFF>(a128);
-        else if (q == 1) v = dsr128<OFF + 256>(a128);
-        else if (q == 2) v = dsr128<OFF + 512>(a128);
-        else v = dsr128<OFF + 768>(a128);
-        b[4 * q + 0] = v[0]; b[4 * q + 1] = v[1]; b[4 * q + 2] = v[2]; b[4 * q + 3] = v[3];
-    }
-    if (REM >= 2) {
-        const f32x2 v = dsr64<OFF + 256 * B4>(a64);
-        b[4 * B4 + 0] = v[0]; b[4 * B4 + 1] = v[1];
-    }
-    if (REM == 1) b[4 * B4] = dsr32<OFF + 256 * B4>(a32);
-    if (REM == 3) b[4 * B4 + 2] = dsr32<OFF + 256 * B4 + 128>(a32);
-}
-
-template <int ST, int STEPS, int NT, int SLJ, int MS, int MAXS, int COUT, class Aux>
-struct PipeStep {
-    static __device__ __forceinline__ void run(uint32_t a128, uint32_t a64, uint32_t a32, const float4 (&a)[MAXS][SLJ],
-                                               f32x4 (&acc)[MAXS][NT], float (&b)[2][NT], Aux &aux) {
-        constexpr int jj = ST >> 2, e = ST & 3;
-        constexpr int RPS = b_reads(NT);
-        if (ST + 1 < STEPS) {
-            constexpr int jn = (ST + 1) >> 2, en = (ST + 1) & 3;
-            read_b<NT, (16 * jn + en) * COUT * 4>(a128, a64, a32, b[(ST + 1) & 1]);
-        }
-        aux(ST);                       // the caller's slot: weight-slice DMA / a gather / tile reads of the write-back
-        if (ST + 1 < STEPS) lgkm_wait<RPS>(); else lgkm_wait<0>();
-#pragma unroll
-        for (int m = 0; m < MS; m++) {
-            const float av = e == 0 ? a[m][jj].x : e == 1 ? a[m][jj].y : e == 2 ? a[m][jj].z : a[m][jj].w;
-#pragma unroll
-            for (int n = 0; n < NT; n++) acc[m][n] = mfma16(av, b[ST & 1][n], acc[m][n]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        PipeStep<ST + 1, STEPS, NT, SLJ, MS, MAXS, COUT, Aux>::run(a128, a64, a32, a, acc, b, aux);
-    }
-};
-template <int STEPS, int NT, int SLJ, int MS, int MAXS, int COUT, class Aux>
-struct PipeStep<STEPS, STEPS, NT, SLJ, MS, MAXS, COUT, Aux> {
-    static __device__ __forceinline__ void run(uint32_t, uint32_t, uint32_t, const float4 (&)[MAXS][SLJ], f32x4 (&)[MAXS][NT],
-                                               float (&)[2][NT], Aux &) {}
-};
-
-// one (k, slice) phase of a wave holding MS sub-chunks (MS = 0: none -- only the auxiliary slots run)
-template <int NT, int SLJ, int MS, int MAXS, int COUT, class Aux>
-__device__ __forceinline__ void pipe_phase(const float *__restrict__ wb, const float4 (&a)[MAXS][SLJ], f32x4 (&acc)[MAXS][NT],
-                                           int g, int r16, Aux &aux) {
-    constexpr int STEPS = 4 * SLJ;
-    if (MS == 0) {
-#pragma unroll
-        for (int st = 0; st < STEPS; st++) aux(st);
-        // An idle wave has nothing else to do than wait for what it has just issued (it would at the phase barrier), and
-        // the wait must be one the compiler SEES (a real S_WAITCNT: vmcnt(0), other counters untouched): hipcc lowers the
-        // dispatch on ms to  if (ms == 0) {..}  if (ms == 1) {..}  one behind the other, and without it its waitcnt pass takes
-        // this path's gathers as possibly pending where the busy path's MFMAs reuse their registers -- and puts a
-        // vmcnt(0), a full memory latency behind the weight DMA just issued, into the middle of the MFMA block.
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        return;
-    }
-    const uint32_t row0 = lds_off(wb + (4 * g) * COUT);
-    const uint32_t a128 = row0 + 16 * r16, a64 = row0 + 8 * r16, a32 = row0 + 4 * r16;
-    float b[2][NT];
-    read_b<NT, 0>(a128, a64, a32, b[0]);
-    PipeStep<0, STEPS, NT, SLJ, MS, MAXS, COUT, Aux>::run(a128, a64, a32, a, acc, b, aux);
-}
-
 template <int MAXS>
 struct RuleIdx {
     int src[MAXS];        // lane r16: src row of rule slot r16 (A operand row); RAW load, see valid()
@@ -360,9 +253,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : occ_for(MAXS, NT, SLJ))) vo
 #pragma unroll
             for (int jj = 0; jj < SLJ; jj++) {
                 a_c[m][jj] = load_a(X, ic.row(m), CIN, 16 * jj + 4 * g);
-#ifdef SEI_DEFER_SELECT
-                if (ic.row(m) < 0) a_c[m][jj] = make_float4(0.f, 0.f, 0.f, 0.f);
-#endif
                 a_n[m][jj] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         int phase = 0;
@@ -401,60 +291,15 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : occ_for(MAXS, NT, SLJ))) vo
                 STAMP(1);
                 // prefetch the next phase's weight slice and A fragments while this one computes
                 const bool same_k = s + 1 < NS;
-                const float *wnext = W + ((size_t)(same_k ? k : kw) * CIN + (size_t)(same_k ? s + 1 : 0) * SL) * COUT;
-                float *wdst = wbuf + (size_t)((phase + 1) & 1) * SL * COUT;
+#ifndef SEI_ABL_NODMA
+                stage_slice<PIECES, NW>(W + ((size_t)(same_k ? k : kw) * CIN + (size_t)(same_k ? s + 1 : 0) * SL) * COUT,
+                                    wbuf + (size_t)((phase + 1) & 1) * SL * COUT, wave, lane);
+#endif
                 const int aoff = (same_k ? (s + 1) * SL : 0) + 4 * g;
 #ifdef SEI_TILE_SKIP  // experiment: gather only the sub-chunks the wave owns in that phase
                 const int msn = same_k ? ic.ms : in1.ms;
 #else
                 const int msn = MAXS;
-#endif
-                const float *wb = wbuf + (size_t)(phase & 1) * SL * COUT + col0;
-#ifdef SEI_PIPE
-                // the phase's other work is issued from the slots BETWEEN the MFMA steps (pipe_phase): slot 0 the weight
-                // slice DMA, slots 1.. one gather each (whatever is left over in the last slot)
-                auto aux = [&](int st) {
-                    constexpr int STEPS = 4 * SLJ;
-#ifndef SEI_ABL_NODMA
-                    if (st == 0) stage_slice<PIECES, NW>(wnext, wdst, wave, lane);
-#endif
-#pragma unroll
-                    for (int m = 0; m < MAXS; m++)
-#pragma unroll
-                        for (int jj = 0; jj < SLJ; jj++) {
-                            const int p = m * SLJ + jj + 1;   // the slot of this gather
-                            if ((p == st || (st == STEPS - 1 && p > st)) && (m == 0 || m < msn))
-                                a_n[m][jj] = load_a(X, same_k ? ic.row(m) : in1.row(m), CIN, aoff + 16 * jj);
-                        }
-                };
-                STAMP(2);
-                TRACE(1);
-                {   // exclusive paths, and only the sub-chunk counts this instantiation can hold
-                    const int msu = __builtin_amdgcn_readfirstlane(ic.ms);
-                    if (msu == 0) pipe_phase<NT, SLJ, 0, MAXS, COUT>(wb, a_c, acc, g, r16, aux);
-                    else if (MAXS == 1 || msu == 1) pipe_phase<NT, SLJ, 1, MAXS, COUT>(wb, a_c, acc, g, r16, aux);
-                    else if (MAXS == 2 || msu == 2) pipe_phase<NT, SLJ, (MAXS >= 2 ? 2 : 1), MAXS, COUT>(wb, a_c, acc, g, r16, aux);
-                    else if (MAXS == 3 || msu == 3) pipe_phase<NT, SLJ, (MAXS >= 3 ? 3 : 1), MAXS, COUT>(wb, a_c, acc, g, r16, aux);
-                    else pipe_phase<NT, SLJ, (MAXS >= 4 ? 4 : 1), MAXS, COUT>(wb, a_c, acc, g, r16, aux);
-                }
-#else
-#ifndef SEI_ABL_NODMA
-#ifdef SEI_IDLE_DMA
-                {   // the waves without a sub-chunk in this phase load the next weight slice (all of them, if every wave is busy)
-                    const int nsub = __builtin_amdgcn_readfirstlane(seg[k + 1] - seg[k]);
-                    const int nbusy = (nsub < U ? nsub : U) * CS;
-                    if (nbusy >= NW) stage_slice<PIECES, NW>(wnext, wdst, wave, lane);
-                    else stage_slice_by<PIECES>(wnext, wdst, wave - nbusy, NW - nbusy, lane);
-                }
-#else
-                stage_slice<PIECES, NW>(wnext, wdst, wave, lane);
-#endif
-#endif
-#ifdef SEI_STAGGER
-                // the second half of the workgroup's waves (the SIMD partners of the first half) computes FIRST and gathers
-                // afterwards: partners then want the matrix pipe and the vector-memory path at different times
-                const bool late = NW == 8 && wave >= NW / 2;
-                if (!late)
 #endif
 #pragma unroll
                 for (int m = 0; m < MAXS; m++)
@@ -463,6 +308,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : occ_for(MAXS, NT, SLJ))) vo
                         for (int jj = 0; jj < SLJ; jj++)
                             a_n[m][jj] = load_a(X, same_k ? ic.row(m) : in1.row(m), CIN, aoff + 16 * jj);
                     }
+                const float *wb = wbuf + (size_t)(phase & 1) * SL * COUT + col0;
                 STAMP(2);
                 TRACE(1);
                 if (MAXS == 1) {
@@ -479,35 +325,14 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : occ_for(MAXS, NT, SLJ))) vo
                         default: break;
                     }
                 }
-#ifdef SEI_STAGGER
-                if (late) {
-#pragma unroll
-                    for (int m = 0; m < MAXS; m++)
-                        if (m == 0 || m < msn) {
-#pragma unroll
-                            for (int jj = 0; jj < SLJ; jj++)
-                                a_n[m][jj] = load_a(X, same_k ? ic.row(m) : in1.row(m), CIN, aoff + 16 * jj);
-                        }
-                }
-#endif
-#endif
                 STAMP(3);
                 TRACE(2 | (ic.ms << 2));
                 STAMP_ADD(8, 1);
                 STAMP_ADD(9, ic.ms * NT * 4 * SLJ);
 #pragma unroll
-                for (int m = 0; m < MAXS; m++) {
-#ifdef SEI_DEFER_SELECT
-                    // padding slots feed zeros (conv_tile.h: load_a); applied HERE, when the gathered values are first
-                    // needed, not behind the load
-                    const bool pad = (same_k ? ic.row(m) : in1.row(m)) < 0;
-#pragma unroll
-                    for (int jj = 0; jj < SLJ; jj++) a_c[m][jj] = pad ? make_float4(0.f, 0.f, 0.f, 0.f) : a_n[m][jj];
-#else
+                for (int m = 0; m < MAXS; m++)
 #pragma unroll
                     for (int jj = 0; jj < SLJ; jj++) a_c[m][jj] = a_n[m][jj];
-#endif
-                }
                 phase++;
                 STAMP(4);
             }

@@ -2,10 +2,6 @@
 #pragma once
 #include "common.h"
 
-#if defined(SEI_PIPE) || defined(SEI_STAGGER)
-#define SEI_DEFER_SELECT 1   // load_a returns the raw rows; the tile kernel zeroes padding slots when it rotates the fragments
-#endif
-
 namespace sei {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -44,8 +40,7 @@ __device__ inline float4 load_a(const float *__restrict__ X, int src, int CIN, i
 #else
     float4 v = *reinterpret_cast<const float4 *>(X + (size_t)row * CIN + off);
 #endif
-#if !defined(SEI_TILE_NOSELECT) && !defined(SEI_DEFER_SELECT)   // SEI_PIPE: the caller selects when it rotates the fragments (a select
-    // here is scheduled right behind the load inside its issue slot and waits for it)
+#ifndef SEI_TILE_NOSELECT
     // Padding slots feed ZEROS to the MFMA.  Their output rows are never written back, so garbage would be equally
     // correct -- but measured on one device (tools/tile_ab.sh, levels 1-3) zeros run 5-7 % faster than row-0 data
     // (51.7 / 66.1 / 71.8 vs 49.2 / 61.9 / 68.5 TFLOP/s): the chip holds a higher clock on the ~10 % all-zero rows.
@@ -68,21 +63,6 @@ __device__ __forceinline__ void stage_slice(const float *__restrict__ wslice, fl
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gp,
                                              (__attribute__((address_space(3))) void *)lp, 16, 0, 0);
         }
-    }
-}
-
-// The same slice dealt to n LOADER waves only (rank = this wave's position among them, < 0: not a loader).  The
-// workgroup-tile kernel passes the waves that hold NO sub-chunk in the running phase: a busy wave then issues no
-// weight DMA at all (each piece costs it an M0 set-up and 100-200 cycles of issue in front of its MFMA block), the waves
-// that would only wait at the barrier do.
-template <int PIECES>
-__device__ __forceinline__ void stage_slice_by(const float *__restrict__ wslice, float *wdst, int rank, int n, int lane) {
-    if (rank < 0) return;   // wave-uniform
-    for (int piece = rank; piece < PIECES; piece += n) {
-        const float *gp = wslice + (size_t)piece * 256 + lane * 4;
-        float *lp = wdst + (size_t)piece * 256;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gp,
-                                         (__attribute__((address_space(3))) void *)lp, 16, 0, 0);
     }
 }
 
