@@ -202,8 +202,27 @@ __device__ __forceinline__ DwOps<MT, NT> dw_load_ops(const DwItem &it, int q, in
     return o;
 }
 
+// Waves per SIMD the register allocator is held to (1: its own choice).  Left alone hipcc splits these kernels' registers
+// into VGPRs + AGPRs with a total just past an occupancy step: 160 planes (2 x 10 tiles) 180 registers = 2 waves per SIMD,
+// held to 3 it fits 163 without scratch and runs 1.365 vs 1.454 ms (level 4, 64 events); 64 planes (4 x 4) 148 = 3 waves,
+// held to 4: 127 registers, 1.94 vs 1.99 ms; 192 planes (2 x 12) 252 = 2 waves, held to 3: 160 registers, 0.655 vs 0.726 ms.
+// Not every step pays: 128 planes (2 x 8) at 4 waves instead of 3 measured 3 % SLOWER, 96 planes (2 x 6) at 5 needs scratch
+// and loses 5 % (profiles/r04_conv_dw_occupancy.log).
+constexpr int dw_min_waves(int mt, int nt) {
+    if (mt == 2 && nt == 10) return 3;
+    if (mt == 2 && nt == 12) return 3;
+    if (mt == 4 && nt == 4) return 4;
+#if defined(SEI_DW_OCC)   // experiment builds: the steps that did not pay
+    if (mt == 2 && nt == 8) return 4;
+#if SEI_DW_OCC >= 2
+    if (mt == 2 && nt == 6) return 5;
+#endif
+#endif
+    return 1;
+}
+
 template <int MT, int NT>
-__global__ __launch_bounds__(256) void conv_dw_mfma_kernel(
+__global__ __launch_bounds__(256, dw_min_waves(MT, NT)) void conv_dw_mfma_kernel(
     const float *__restrict__ X, const float *__restrict__ dY, const int32_t *__restrict__ tile_sub_start,
     const int32_t *__restrict__ seg_start, const int32_t *__restrict__ sub_src, const uint8_t *__restrict__ sub_dst,
     int n_tiles, int TR, int CIN, int COUT, int tiles_per_split, int S, int K, float *__restrict__ slab) {

@@ -176,8 +176,17 @@ constexpr int occ_for(int maxs, int nt, int slj) {
 // LDS: acc[TR][COUT] | wbuf[2][SL][COUT] | seg[K+1]
 constexpr int APAD = 0;  // the shared tile helpers (conv_tile.h) assume an unpadded accumulator row stride
 
+// Eight-wave workgroups: two per CU (4 waves per SIMD, 128 registers) always fit; where the LDS of THREE fits (the 128- and
+// 160-column layers in two column blocks: 40 / 50 KB) the third one is worth 15 % (profiles/r04_conv_tile_experiments.log: every
+// source variant that pushed the 128-column kernel from 80 to 86+ registers lost exactly that), so the allocator is held to
+// 6 waves per SIMD = 80 registers there instead of landing on the step by luck.
+constexpr int occ8_for(int nt, int cs, int slj, int maxs) {
+    const int cout = 16 * nt * cs, tr = 16 * maxs * (8 / cs);
+    return 3 * (tr * cout + 2 * 16 * slj * cout) * 4 + 3 * 128 <= 160 * 1024 ? 6 : 4;
+}
+
 template <int NT, int CS, int SLJ, int MAXS, int NW = 4>
-__global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : occ_for(MAXS, NT, SLJ))) void conv_tile_mfma_kernel(
+__global__ __launch_bounds__(64 * NW, (NW == 8 ? occ8_for(NT, CS, SLJ, MAXS) : occ_for(MAXS, NT, SLJ))) void conv_tile_mfma_kernel(
     const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ Y,
     const int32_t *__restrict__ tile_sub_start, const int32_t *__restrict__ tile_seg,
     const int32_t *__restrict__ sub_src, const uint8_t *__restrict__ sub_dst, int64_t n_dst, int K, int CIN, int n_tiles,
