@@ -317,7 +317,9 @@ def main():
                 # HBM traffic cannot be read live: it comes from the committed PMC passes of this same command
                 # (tools/traffic.sh); the file's git blob hash is emitted beside it so that a stale file shows
                 traffic = traffic_src = None
-                tname = "r03_conv_fwd_hbm_traffic.json"
+                import glob
+                found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r??_conv_fwd_hbm_traffic.json")))
+                tname = os.path.basename(found[-1]) if found else "none"   # the latest round's passes
                 tpath = os.path.join(ROOT, "profiles", tname)
                 if (os.path.exists(tpath) and args.model == "dune3d" and args.mode == "train" and args.batch == 64
                         and args.voxels == 50000 and args.kind == "tracks" and grid == (900, 900, 900)):

@@ -38,7 +38,7 @@ res = {"commit": os.environ.get("SEI_COMMIT"),
        "per_variant_raw_fetch_write_mb": {k: [fa[k] * 1024 / fc[k] / 1e6, wa[k] * 1024 / max(wc[k], 1) / 1e6, fc[k]] for k in sorted(conv + dw)},
        "conv_dw_mfma_kernel": {"launches": nd, "fetch_size_bytes_per_launch": fd, "write_size_bytes_per_launch": wd,
                                "traffic_bytes_per_launch": 2 * fd + wd}}
-json.dump(res, open("gpurun_out/r03_conv_fwd_hbm_traffic.json", "w"), indent=1)
+json.dump(res, open("gpurun_out/%s_conv_fwd_hbm_traffic.json" % os.environ.get("SEI_ROUND", "r04"), "w"), indent=1)
 print(json.dumps(res, indent=1))
 PY
 rm -rf $out/f $out/w
