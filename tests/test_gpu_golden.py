@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.util import rel_err
+from tests.util import elem_close, rel_err
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -28,5 +28,6 @@ def test_encoder_matches_golden_fixture():
     assert rel_err(dense, g["dense"]) < 1e-4                     # north_star tolerance, fp32
     for k in HEADS:
         assert rel_err(logits[k], g["logits_" + k]) < 1e-4
+        assert elem_close(logits[k], g["logits_" + k])[0], k
     loss = focal_loss(logits, {k: torch.from_numpy(g["label_" + k]).cuda() for k in HEADS})
     assert abs(float(loss.detach()) - float(g["loss"])) < 1e-4

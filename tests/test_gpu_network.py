@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle import scn_cpu
-from tests.util import blob_cloud, rel_err
+from tests.util import elem_close, blob_cloud, rel_err
 
 pytestmark = pytest.mark.gpu
 HEADS = {"labelneutID": 3, "labelprotID": 3, "labelnpiID": 2, "labelcpiID": 2}
@@ -62,6 +62,7 @@ def test_encoder_head_loss_parity(dimension, image_size, kw):
     assert rel_err(dense, odense) < 1e-4
     for k in HEADS:
         assert rel_err(logits[k], ologits[k]) < 1e-4
+        assert elem_close(logits[k], ologits[k])[0], (k, elem_close(logits[k], ologits[k])[1])   # every logit
     assert abs(float(loss.detach()) - float(oloss.detach())) < 1e-4 * max(1.0, abs(float(oloss.detach())))
     named = dict(enc.named_parameters())
     named.update({"classification_head." + k[len("classification_head."):] if k.startswith("classification_head.") else k: v
@@ -118,5 +119,6 @@ def test_fused_sparse_head_equals_dense_path_and_oracle():
     for k in HEADS:
         assert rel_err(fused_logits[k], dense_logits[k]) < 1e-5
         assert rel_err(fused_logits[k], ologits[k]) < 1e-4
+        assert elem_close(fused_logits[k], ologits[k])[0], (k, elem_close(fused_logits[k], ologits[k])[1])
     assert rel_err(enc.bottleneck.weight.grad, g_dense) < 1e-4
     assert rel_err(enc.bottleneck.weight.grad, osd["bottleneck.weight"].grad) < 1e-4

@@ -292,3 +292,46 @@ def test_eval_step_between_training_steps_keeps_the_training_template():
     levels = 2
     assert out["batched"][1] == 1 + levels + 1 and out["batched"][2] == 1 + levels + 1, out["batched"][1:]
     assert torch.equal(lazy.arena.flat, batched.arena.flat)
+
+
+def test_deferred_join_from_another_stream_waits_for_the_side_stream():
+    """Mode 2 (deferred join): the backward pass runs under stream A, the caller then switches to stream B and joins THERE
+    (an optimizer on its own stream).  sei_backward_join joins every side stream of the device with un-joined work into the
+    joining stream, so the weight gradients read under B are the finished ones: equal to the serial run's, bit for bit.
+    (It used to look up only the side stream paired with the joining stream, find none, and return without waiting.)"""
+    import sparseeventid_amd.scn as scn
+    sp, B, C = [40, 36, 38], 2, 96
+    coords, feats = blob_cloud(91, B, sp, 6000, 1)
+    t = scn.InputLayer(3, sp)((torch.from_numpy(coords), torch.from_numpy(feats).cuda(), B))
+    n = t.features.shape[0]
+    torch.manual_seed(4)
+    convs = [scn.SubmanifoldConvolution(3, C, C, 3, False).cuda() for _ in range(6)]
+    x = torch.randn(n, C, device="cuda")
+    gy = torch.randn(n, C, device="cuda")
+
+    def run():
+        for c in convs:
+            c.weight.grad = None
+        h = scn.SparseConvNetTensor(x.clone().requires_grad_(True), t.metadata, t.spatial_size)
+        for c in convs:
+            h = c(h)
+        h.features.backward(gy)
+
+    run()
+    torch.cuda.synchronize()
+    want = [c.weight.grad.clone() for c in convs]
+    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    scn.set_backward_streams(2)
+    try:
+        a.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(a):
+            run()
+        b.wait_stream(a)                       # orders B behind the dX chain, NOT behind the library's dW side stream
+        with torch.cuda.stream(b):
+            scn.backward_join([c.weight for c in convs])
+            got = [c.weight.grad.clone() for c in convs]   # read under B right behind the join
+        torch.cuda.synchronize()
+    finally:
+        scn.set_backward_streams(0)
+    for w, g in zip(want, got):
+        assert torch.equal(w, g)

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle import scn_cpu
-from tests.util import rel_err
+from tests.util import elem_close, rel_err
 
 pytestmark = pytest.mark.gpu
 OUT = {"label_cpi": 2, "label_prot": 3}
@@ -57,6 +57,7 @@ def test_sbnd_network_parity():
     for k in OUT:
         assert out[k].shape == (B, OUT[k])
         assert rel_err(out[k], oout[k]) < 1e-4
+        assert elem_close(out[k], oout[k])[0], (k, elem_close(out[k], oout[k])[1])   # every class score
     named = dict(net.named_parameters())
     gmax = max(float(osd[k].grad.abs().max()) for k in named)
     for k, p in named.items():

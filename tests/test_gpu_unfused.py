@@ -13,7 +13,7 @@ import pytest
 import torch
 
 from oracle import scn_cpu
-from tests.util import blob_cloud, rel_err
+from tests.util import elem_close, blob_cloud, rel_err
 
 pytestmark = pytest.mark.gpu
 HEADS = {"labelneutID": 3, "labelprotID": 3, "labelnpiID": 2, "labelcpiID": 2}
@@ -106,6 +106,7 @@ def test_reference_style_unfused_encoder_matches_oracle_and_fused_path():
     assert rel_err(dense, odense) < 1e-4
     for k in HEADS:
         assert rel_err(logits[k], ologits[k]) < 1e-4
+        assert elem_close(logits[k], ologits[k])[0], (k, elem_close(logits[k], ologits[k])[1])   # every logit
     assert abs(loss - float(oloss.detach())) < 1e-4 * max(1.0, abs(float(oloss.detach())))
     gmax = max(float(osd[k].grad.abs().max()) for k in grads)
     for k, gk in grads.items():

@@ -60,3 +60,12 @@ def rel_err(a, b):
     a = a.detach().cpu().double() if isinstance(a, torch.Tensor) else torch.as_tensor(a).double()
     b = b.detach().cpu().double() if isinstance(b, torch.Tensor) else torch.as_tensor(b).double()
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def elem_close(a, b, rtol=1e-4, atol=1e-6):
+    """Element-wise  |a - b| <= rtol |b| + atol  (the strict reading of "1e-4 relative": every element, not only against
+    the largest one as rel_err does).  Returns (ok, worst relative deviation) for the assertion message."""
+    a = a.detach().cpu().double() if isinstance(a, torch.Tensor) else torch.as_tensor(a).double()
+    b = b.detach().cpu().double() if isinstance(b, torch.Tensor) else torch.as_tensor(b).double()
+    d = (a - b).abs()
+    return bool((d <= rtol * b.abs() + atol).all()), float((d / b.abs().clamp_min(atol)).max())
