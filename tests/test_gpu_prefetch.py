@@ -335,3 +335,78 @@ def test_deferred_join_from_another_stream_waits_for_the_side_stream():
         scn.set_backward_streams(0)
     for w, g in zip(want, got):
         assert torch.equal(w, g)
+
+
+def test_lazy_build_waits_for_a_batch_build_in_flight():
+    """Two host threads, two streams: one runs sei_metadata_prebuild_like (begins every variant, releases the rulebooks'
+    mutexes around its one read-back, finishes them), the other asks for the same variants lazily at the same time (the
+    autograd thread does when a prefetch overlaps a backward pass).  A begun variant is marked and the lazy call waits for
+    it instead of starting a second build into the same slot: same rule counts as an undisturbed build, and the device pool
+    holds no more afterwards than after one (a second build used to leak its arrays)."""
+    import ctypes
+    import threading
+    import sparseeventid_amd.scn as scn
+    from sparseeventid_amd._lib import lib
+    sp = [28, 26, 24]
+    ca, fa = blob_cloud(15, 2, sp, 900, 1)
+    layer = scn.InputLayer(3, sp)
+    ta = layer((torch.from_numpy(ca), torch.from_numpy(fa).cuda(), 2))
+    variants = (64, 128, 256)
+    for f in ([3, 3, 3], [5, 5, 5]):
+        for v in variants:
+            ta.metadata.subm_rulebook(sp, f).stats(v)
+    torch.cuda.synchronize()
+
+    def pool_in_use():
+        held, used = ctypes.c_int64(), ctypes.c_int64()
+        assert lib().sei_pool_stats(ctypes.byref(held), ctypes.byref(used)) == 0
+        return used.value
+
+    want = None
+    for it in range(6):
+        cb, fb = blob_cloud(40 + it, 2, sp, 700 + 50 * it, 1)
+        tb = layer((torch.from_numpy(cb), torch.from_numpy(fb).cuda(), 2))
+        rbs = [tb.metadata.subm_rulebook(sp, f) for f in ([3, 3, 3], [5, 5, 5])]
+        errs = []
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        s1.wait_stream(torch.cuda.current_stream()); s2.wait_stream(torch.cuda.current_stream())
+        go = threading.Barrier(2)
+
+        def batch():
+            try:
+                with torch.cuda.stream(s1):
+                    go.wait()
+                    tb.metadata.prebuild_like(ta.metadata)
+            except Exception as e:   # noqa: BLE001
+                errs.append(e)
+
+        def lazy():
+            try:
+                with torch.cuda.stream(s2):
+                    go.wait()
+                    for rb in rbs:
+                        for v in variants:
+                            check_rc = lib().sei_rulebook_build(rb.h, v, ctypes.c_void_p(s2.cuda_stream))
+                            assert check_rc == 0
+            except Exception as e:   # noqa: BLE001
+                errs.append(e)
+
+        th = [threading.Thread(target=batch), threading.Thread(target=lazy)]
+        for t_ in th:
+            t_.start()
+        for t_ in th:
+            t_.join(60)
+            assert not t_.is_alive(), "a build is stuck"
+        torch.cuda.synchronize()
+        assert not errs, errs
+        got = [rb.stats(64)[:3] for rb in rbs]       # (rules, sub-chunks, tiles) of the 64-row variant
+        # the same batch built undisturbed
+        tc = layer((torch.from_numpy(cb), torch.from_numpy(fb).cuda(), 2))
+        ref = [tc.metadata.subm_rulebook(sp, f).stats(64)[:3] for f in ([3, 3, 3], [5, 5, 5])]
+        assert got == ref, (it, got, ref)
+        del tb, tc, rbs
+        torch.cuda.synchronize()
+        used = pool_in_use()
+        if want is None:
+            want = used
+        assert used <= want + (1 << 20), (it, used, want)   # nothing accumulates from one round to the next
