@@ -84,6 +84,13 @@ int sei_metadata_prebuild_like(sei_metadata_t *m, sei_metadata_t *like, sei_stre
  * FORWARD convolution of `like` fetched -- not the transposed rules of the strided layers (dX) nor the weight-gradient
  * kernel's own variants. */
 int sei_metadata_prebuild_forward_like(sei_metadata_t *m, sei_metadata_t *like, sei_stream_t stream);
+/* sei_input_build for a batch whose network is known from the metadata `like` of an earlier batch: the input level and the
+ * whole chain of strided levels `like` holds are discovered back to back with their row counts kept on the device, and ONE
+ * stream synchronisation gives the host all of them (sei_input_build followed by sei_metadata_prebuild_like needs one for
+ * the InputLayer and one for the levels).  A later sei_metadata_prebuild_like(m, like) then only builds the tiled variants
+ * (one more synchronisation): two per batch in all.  `like` == NULL: plain sei_input_build. */
+int sei_input_build_like(sei_metadata_t *m, const int32_t *coords_dev, int64_t n_points, const int32_t spatial[3],
+                         int32_t batch_size, int32_t mode, sei_metadata_t *like, sei_stream_t stream, int64_t *n_rows);
 
 /* ---- rulebooks (SCN `getSubmanifoldRuleBook` / `getRuleBook`) ---------------------------- */
 /* Cached in the metadata per (spatial, filter).  Synchronises `stream` on first build. */

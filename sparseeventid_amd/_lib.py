@@ -22,6 +22,7 @@ _SIGNATURES = {
     "sei_metadata_create": (ctypes.c_int, [ctypes.POINTER(vp)]),
     "sei_metadata_destroy": (None, [vp]),
     "sei_input_build": (ctypes.c_int, [vp, vp, ctypes.c_int64, c_i32p, ctypes.c_int32, ctypes.c_int32, vp, c_i64p]),
+    "sei_input_build_like": (ctypes.c_int, [vp, vp, ctypes.c_int64, c_i32p, ctypes.c_int32, ctypes.c_int32, vp, vp, c_i64p]),
     "sei_larcv_to_scn": (ctypes.c_int, [vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp, vp, vp,
                                         c_i64p]),
     "sei_input_features_fwd": (ctypes.c_int, [vp, vp, ctypes.c_int32, vp, vp]),

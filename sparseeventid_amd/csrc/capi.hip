@@ -460,8 +460,11 @@ int sei_subm_rulebook(sei_metadata_t *m, const int32_t spatial[3], const int32_t
     return 0;
 }
 
-int sei_conv_rulebook(sei_metadata_t *m, const int32_t spatial_in[3], const int32_t size[3], const int32_t stride[3],
-                      sei_stream_t stream, sei_rulebook_t **rb_out, int32_t spatial_out[3]) {
+// scn.Convolution's rulebook: finds it, or creates it and BEGINS the discovery of its output level (build_strided_level_begin:
+// nothing synchronised yet; *pl says whether a finish is owed)
+static int conv_rulebook_begin(sei_metadata_t *m, const int32_t spatial_in[3], const int32_t size[3], const int32_t stride[3],
+                               hipStream_t st, sei_rulebook_t **rb_out, int32_t spatial_out[3], PendingLevel *pl) {
+    *pl = PendingLevel();
     std::lock_guard<std::mutex> lk(m->mu);
     for (auto *rb : m->rulebooks)
         if (!rb->submanifold && same3(rb->spatial_in, spatial_in) && same3(rb->size, size) && same3(rb->stride, stride)) {
@@ -478,7 +481,7 @@ int sei_conv_rulebook(sei_metadata_t *m, const int32_t spatial_in[3], const int3
         rb->size[d] = size[d];
         rb->stride[d] = stride[d];
     }
-    int rc = build_strided_level(m, l, size, stride, rb, (hipStream_t)stream);
+    int rc = build_strided_level_begin(m, l, size, stride, rb, st, pl);
     if (rc) {
         delete rb;
         return rc;
@@ -489,37 +492,94 @@ int sei_conv_rulebook(sei_metadata_t *m, const int32_t spatial_in[3], const int3
     return 0;
 }
 
+int sei_conv_rulebook(sei_metadata_t *m, const int32_t spatial_in[3], const int32_t size[3], const int32_t stride[3],
+                      sei_stream_t stream, sei_rulebook_t **rb_out, int32_t spatial_out[3]) {
+    PendingLevel pl;
+    SEI_TRY(conv_rulebook_begin(m, spatial_in, size, stride, (hipStream_t)stream, rb_out, spatial_out, &pl));
+    if (pl.pending && sync_stream((hipStream_t)stream) != hipSuccess) SEI_FAIL("rulebook: hipStreamSynchronize failed");
+    return build_strided_level_finish(&pl);
+}
+
+extern "C++" {
+namespace {
+struct LikeItem {
+    bool subm;
+    int32_t sp[3], size[3], stride[3];
+    bool fwd[SEI_NVARIANT], bwd[SEI_NVARIANT], fuse[SEI_NVARIANT];
+};
+
+// what the metadata of an earlier batch holds: its rulebooks in creation order (= the order of its forward pass: strided
+// rulebooks create the levels later ones need) and which tiled variants of each exist
+std::vector<LikeItem> like_items(sei_metadata_t *like) {
+    std::vector<LikeItem> items;
+    std::lock_guard<std::mutex> lk(like->mu);
+    for (auto *rb : like->rulebooks) {
+        std::lock_guard<std::mutex> lr(rb->mu);
+        LikeItem it;
+        it.subm = rb->submanifold;
+        for (int d = 0; d < 3; d++) { it.sp[d] = rb->spatial_in[d]; it.size[d] = rb->size[d]; it.stride[d] = rb->stride[d]; }
+        for (int v = 0; v < SEI_NVARIANT; v++) {
+            it.fwd[v] = rb->fwd[v].built; it.bwd[v] = rb->bwd[v].built; it.fuse[v] = rb->fwd[v].fwd_use;
+        }
+        items.push_back(it);
+    }
+    return items;
+}
+
+// Every rulebook of the list, the strided ones only BEGUN: a level discovered behind an unfinished one reads that one's row
+// count from the device, so the whole chain of levels is queued back to back; the caller synchronises ONCE and finishes
+// them (finish_levels).  Stops at the first failure (a level of the template that does not exist for this batch).
+int begin_rulebooks(sei_metadata_t *m, const std::vector<LikeItem> &items, hipStream_t st, std::vector<sei_rulebook_t *> *made,
+                    std::vector<PendingLevel> *levels) {
+    made->assign(items.size(), nullptr);
+    for (size_t i = 0; i < items.size(); i++) {
+        const LikeItem &it = items[i];
+        int32_t spo[3];
+        if (it.subm) {
+            SEI_TRY(sei_subm_rulebook(m, it.sp, it.size, (sei_stream_t)st, &(*made)[i]));
+        } else {
+            PendingLevel pl;
+            SEI_TRY(conv_rulebook_begin(m, it.sp, it.size, it.stride, st, &(*made)[i], spo, &pl));
+            if (pl.pending) levels->push_back(pl);
+        }
+    }
+    return 0;
+}
+
+// in order: every begun level gets its host row count (also when a later item failed)
+int finish_levels(std::vector<PendingLevel> *levels) {
+    int rc = 0;
+    for (PendingLevel &pl : *levels) {
+        const int r = build_strided_level_finish(&pl);
+        if (!rc) rc = r;
+    }
+    levels->clear();
+    return rc;
+}
+}  // namespace
+}  // extern "C++"
+
 static int prebuild_like_impl(sei_metadata_t *m, sei_metadata_t *like, bool forward_only, sei_stream_t stream) {
     if (!m || !like) SEI_FAIL("sei_metadata_prebuild_like: null argument");
     if (m == like) return 0;
-    struct Item {
-        bool subm;
-        int32_t sp[3], size[3], stride[3];
-        bool fwd[SEI_NVARIANT], bwd[SEI_NVARIANT], fuse[SEI_NVARIANT];
-    };
-    std::vector<Item> items;
-    {
-        std::lock_guard<std::mutex> lk(like->mu);
-        for (auto *rb : like->rulebooks) {
-            std::lock_guard<std::mutex> lr(rb->mu);
-            Item it;
-            it.subm = rb->submanifold;
-            for (int d = 0; d < 3; d++) { it.sp[d] = rb->spatial_in[d]; it.size[d] = rb->size[d]; it.stride[d] = rb->stride[d]; }
-            for (int v = 0; v < SEI_NVARIANT; v++) {
-                it.fwd[v] = rb->fwd[v].built; it.bwd[v] = rb->bwd[v].built; it.fuse[v] = rb->fwd[v].fwd_use;
-            }
-            items.push_back(it);
-        }
+    const std::vector<LikeItem> items = like_items(like);
+    // First the rulebooks and levels (ONE read-back for all strided levels that do not exist yet -- none after
+    // sei_input_build_like), then every tiled variant is begun, ONE read-back serves them all, and they are finished: the
+    // forward and backward passes that follow find everything built and synchronise nothing.
+    std::vector<sei_rulebook_t *> made;
+    std::vector<PendingLevel> levels;
+    int rc0 = begin_rulebooks(m, items, (hipStream_t)stream, &made, &levels);
+    if (!levels.empty() && sync_stream((hipStream_t)stream) != hipSuccess && !rc0) {
+        set_error("rulebook: hipStreamSynchronize failed");
+        rc0 = 1;
     }
-    // creation order = the order of the template's forward pass: strided rulebooks create the levels later ones need
-    // (one count read-back per new level); then every tiled variant is begun, ONE read-back serves them all, and they
-    // are finished -- the forward and backward passes that follow find everything built and synchronise nothing
+    const int rf = finish_levels(&levels);
+    if (!rc0) rc0 = rf;
+    if (rc0) return rc0;
     std::vector<TiledRequest> want;
-    for (const Item &it : items) {
-        sei_rulebook_t *rb = nullptr;
-        int32_t spo[3];
-        if (it.subm) SEI_TRY(sei_subm_rulebook(m, it.sp, it.size, stream, &rb));
-        else SEI_TRY(sei_conv_rulebook(m, it.sp, it.size, it.stride, stream, &rb, spo));
+    for (size_t i = 0; i < items.size(); i++) {
+        const LikeItem &it = items[i];
+        sei_rulebook_t *rb = made[i];
         for (int v = 0; v < SEI_NVARIANT; v++) {
             // forward_only: the variants a FORWARD convolution of the template fetched -- not the transposed rules of the
             // strided layers (dX) nor dW's 256-row variants: an evaluation pass between training steps builds nothing it
@@ -529,6 +589,53 @@ static int prebuild_like_impl(sei_metadata_t *m, sei_metadata_t *like, bool forw
         }
     }
     return build_tiled_batch(want, (hipStream_t)stream);
+}
+
+// scn.InputLayer for a batch whose network is known from an EARLIER batch's metadata: the input level and the whole chain
+// of strided levels `like` holds are discovered back to back with their row counts on the device, and ONE stream
+// synchronisation gives the host all of them (sei_input_build + sei_metadata_prebuild_like: one for the InputLayer and one
+// for the levels).  Rulebooks and levels that `like` has and this batch cannot (an event too small for a deep level) are
+// skipped silently here: sei_metadata_prebuild_like / the lazy path report them as before.
+int sei_input_build_like(sei_metadata_t *m, const int32_t *coords_dev, int64_t n, const int32_t spatial[3],
+                         int32_t batch_size, int32_t mode, sei_metadata_t *like, sei_stream_t stream, int64_t *n_rows) {
+    if (!m || !n_rows || (n > 0 && !coords_dev)) SEI_FAIL("sei_input_build_like: null argument");
+    if (mode < 0 || mode > 4) SEI_FAIL("InputLayer: mode must be 0..4");
+    if (!like || like == m) return sei_input_build(m, coords_dev, n, spatial, batch_size, mode, stream, n_rows);
+    hipStream_t st = (hipStream_t)stream;
+    PendingInput pi;
+    {
+        std::lock_guard<std::mutex> lk(m->mu);
+        if (!m->levels.empty()) SEI_FAIL("InputLayer: metadata already holds an input level");
+        m->input_mode = mode;
+        ProfScope ps(PROF_RULES, st, 0.0, 12.0 * n);
+        const int rc = build_input_level_begin(m, coords_dev, n, spatial, batch_size, st, &pi);
+        if (rc) {
+            pool_free(pi.slot_of); pool_free(pi.flag); pool_free(pi.err_total); pool_free(pi.new_vals); stage_put(pi.host);
+            return rc;
+        }
+    }
+    std::vector<sei_rulebook_t *> made;
+    std::vector<PendingLevel> levels;
+    if (pi.pending) {
+        const std::string keep = sei_last_error();
+        (void)begin_rulebooks(m, like_items(like), st, &made, &levels);   // failures: see above
+        set_error(keep);
+    }
+    int rc = 0;
+    if ((pi.pending || !levels.empty()) && sync_stream(st) != hipSuccess) {
+        set_error("InputLayer: hipStreamSynchronize failed");
+        rc = 1;
+    }
+    {
+        std::lock_guard<std::mutex> lk(m->mu);
+        if (rc) {
+            pool_free(pi.slot_of); pool_free(pi.flag); pool_free(pi.err_total); stage_put(pi.host);
+        } else {
+            rc = build_input_level_finish(m, &pi, st, n_rows);
+        }
+    }
+    const int rf = finish_levels(&levels);
+    return rc ? rc : rf;
 }
 
 int sei_metadata_prebuild_like(sei_metadata_t *m, sei_metadata_t *like, sei_stream_t stream) {

@@ -155,7 +155,9 @@ struct HashTable {
 // One resolution level: active sites of one spatial size.
 struct Level {
     int32_t spatial[3] = {0, 0, 0};
-    int64_t n = 0;
+    int64_t n = 0;              // rows (-1 between build_strided_level_begin and _finish: known to the device only)
+    const int32_t *n_dev = nullptr;   // while unfinished: the row count on the device, and its upper bound on the host
+    int64_t n_ub = 0;
     int32_t *coords = nullptr;  // [n,4] device
     HashTable ht;
 };
@@ -229,6 +231,23 @@ Level *find_level(sei_metadata *m, const int32_t spatial[3]);
 int alloc_table(HashTable *ht, int64_t n, hipStream_t st);
 int build_input_level(sei_metadata *m, const int32_t *coords, int64_t n, const int32_t spatial[3], int32_t batch,
                       hipStream_t st, int64_t *n_rows);
+// the same in two halves around its count read-back (hash.hip): strided levels begun between the halves read the input
+// level's row count from the device, and ONE stream synchronisation serves the InputLayer and the whole chain of levels
+struct PendingInput {
+    Level *level = nullptr;
+    uint32_t *slot_of = nullptr, *new_vals = nullptr;
+    int32_t *flag = nullptr, *err_total = nullptr;   // device: [0] first out-of-range point, [1] rows, [2] table-full flag
+    unsigned long long *host = nullptr;              // pinned staging block of those words
+    const int32_t *coords = nullptr;
+    int64_t n = 0;
+    bool pending = false;
+};
+int build_input_level_begin(sei_metadata *m, const int32_t *coords, int64_t n, const int32_t spatial[3], int32_t batch,
+                            hipStream_t st, PendingInput *pi);
+int build_input_level_finish(sei_metadata *m, PendingInput *pi, hipStream_t st, int64_t *n_rows);
+// pinned staging blocks for count read-backs (rulebook.hip), recycled
+unsigned long long *stage_get();
+void stage_put(unsigned long long *p);
 int input_features_fwd(sei_metadata *m, const float *in, int C, float *out, hipStream_t st);
 int input_features_bwd(sei_metadata *m, const float *dout, int C, float *din, hipStream_t st);
 int exclusive_scan_i32(const int32_t *in, int32_t *out, int64_t n, int32_t *total_dev, hipStream_t st);
@@ -252,6 +271,17 @@ struct TiledRequest {
 int build_tiled_batch(const std::vector<TiledRequest> &want, hipStream_t st);
 int build_strided_level(sei_metadata *m, Level *lin, const int32_t size[3], const int32_t stride[3], sei_rulebook *rb,
                         hipStream_t st);
+// the same in two halves around the site-count read-back (rulebook.hip): a chain of levels begun back to back needs ONE
+// stream synchronisation before they are finished in order
+struct PendingLevel {
+    Level *level = nullptr;
+    int32_t *total = nullptr;            // device: [0] output sites, [1] table-full flag
+    unsigned long long *host = nullptr;  // pinned staging block the two words are copied to
+    bool pending = false;
+};
+int build_strided_level_begin(sei_metadata *m, Level *lin, const int32_t size[3], const int32_t stride[3], sei_rulebook *rb,
+                              hipStream_t st, PendingLevel *pl);
+int build_strided_level_finish(PendingLevel *pl);
 int export_rules(const TiledRules &t, int64_t *start_host, int32_t *rin, int32_t *rout, hipStream_t st);
 // conv_fwd.hip / conv_wave.hip
 // How one convolution (forward, or dX with the plane counts swapped) runs: decided ONCE per call from the plane

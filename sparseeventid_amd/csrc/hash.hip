@@ -177,9 +177,13 @@ int alloc_table(HashTable *ht, int64_t n, hipStream_t st) {
     return 0;
 }
 
-// scn.InputLayer coordinate pass.
-int build_input_level(sei_metadata *m, const int32_t *coords, int64_t n, const int32_t spatial[3], int32_t batch,
-                      hipStream_t st, int64_t *n_rows) {
+// scn.InputLayer coordinate pass, in two halves around the ONE read-back of (first bad point, row count, table-full flag):
+//   begin : table, insert, first-appearance flags, scan, rows assigned -- arrays sized for n rows (rows <= points); the row
+//           count stays on the device (Level::n_dev) for strided levels begun behind it
+//   finish: after the stream has been synchronised: errors, host row count, the sorted lists of duplicate points.
+int build_input_level_begin(sei_metadata *m, const int32_t *coords, int64_t n, const int32_t spatial[3], int32_t batch,
+                            hipStream_t st, PendingInput *pi) {
+    *pi = PendingInput();
     for (int d = 0; d < 3; d++)
         if (spatial[d] <= 0 || spatial[d] > 65535) SEI_FAIL("InputLayer: spatial size must be in [1,65535]");
     if (batch <= 0 || batch > 65534) SEI_FAIL("InputLayer: batch size must be in [1,65534]");
@@ -189,82 +193,123 @@ int build_input_level(sei_metadata *m, const int32_t *coords, int64_t n, const i
     m->levels.push_back(lv);
     m->batch_size = batch;
     m->n_input = n;
+    pi->level = lv;
+    pi->coords = coords;
+    pi->n = n;
     if (n == 0) {
         lv->n = 0;
         SEI_TRY(alloc_table(&lv->ht, 0, st));
         SEI_TRY(pool_alloc_t(&lv->coords, 4, st));
-        *n_rows = 0;
         return 0;
     }
     SEI_TRY(alloc_table(&lv->ht, n, st));
-    uint32_t *slot_of, *new_vals;
-    int32_t *flag, *err_total;
-    SEI_TRY(pool_alloc_t(&slot_of, n, st));
-    SEI_TRY(pool_alloc_t(&flag, n, st));
-    SEI_TRY(pool_alloc_t(&err_total, 4, st));  // [0] first out-of-range point, [1] row count, [2] table-full flag
-    SEI_TRY(pool_alloc_t(&new_vals, lv->ht.mask + 1, st));
+    SEI_TRY(pool_alloc_t(&pi->slot_of, n, st));
+    SEI_TRY(pool_alloc_t(&pi->flag, n, st));
+    SEI_TRY(pool_alloc_t(&pi->err_total, 4, st));
+    SEI_TRY(pool_alloc_t(&pi->new_vals, lv->ht.mask + 1, st));
     SEI_TRY(pool_alloc_t(&m->input_row, n, st));
-    SEI_HIP(hipMemsetAsync(err_total, 0xFF, 4 * sizeof(int32_t), st));
-    SEI_HIP(hipMemsetAsync(new_vals, 0xFF, (lv->ht.mask + 1) * sizeof(uint32_t), st));
+    pi->host = stage_get();
+    if (!pi->host) SEI_FAIL("InputLayer: cannot allocate pinned staging memory");
+    SEI_HIP(hipMemsetAsync(pi->err_total, 0xFF, 4 * sizeof(int32_t), st));
+    SEI_HIP(hipMemsetAsync(pi->new_vals, 0xFF, (lv->ht.mask + 1) * sizeof(uint32_t), st));
     const int T = 256;
     const int nb = (int)((n + T - 1) / T);
     input_insert_kernel<<<nb, T, 0, st>>>(coords, n, spatial[0], spatial[1], spatial[2], batch, lv->ht.keys,
-                                          lv->ht.vals, lv->ht.mask, lv->ht.filter, lv->ht.fmask, slot_of, err_total);
-    flag_first_kernel<<<nb, T, 0, st>>>(slot_of, lv->ht.vals, n, flag);
+                                          lv->ht.vals, lv->ht.mask, lv->ht.filter, lv->ht.fmask, pi->slot_of, pi->err_total);
+    flag_first_kernel<<<nb, T, 0, st>>>(pi->slot_of, lv->ht.vals, n, pi->flag);
     SEI_LAUNCH_CHECK();
-    SEI_TRY(exclusive_scan_i32(flag, flag, n, err_total + 1, st));
-    int32_t host[3];
-    SEI_HIP(hipMemcpyAsync(host, err_total, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    SEI_HIP(sync_stream(st));
-    if (host[0] != -1) {
-        pool_free(slot_of); pool_free(flag); pool_free(err_total); pool_free(new_vals);
-        SEI_FAIL("InputLayer: coordinate of input point " + std::to_string((uint32_t)host[0]) +
-                 " is outside spatial_size / batch_size");
+    SEI_TRY(exclusive_scan_i32(pi->flag, pi->flag, n, pi->err_total + 1, st));
+    SEI_HIP(hipMemcpyAsync(pi->host, pi->err_total, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    // rows <= points: the per-row arrays are sized for n
+    SEI_TRY(pool_alloc_t(&lv->coords, 4 * n, st));
+    SEI_TRY(pool_alloc_t(&m->row_first, n, st));
+    SEI_TRY(pool_alloc_t(&m->row_last, n, st));
+    SEI_TRY(pool_alloc_t(&m->row_count, n, st));
+    SEI_HIP(hipMemsetAsync(m->row_last, 0xFF, n * sizeof(int32_t), st));
+    SEI_HIP(hipMemsetAsync(m->row_count, 0, n * sizeof(int32_t), st));
+    assign_rows_kernel<<<nb, T, 0, st>>>(coords, pi->slot_of, lv->ht.vals, pi->flag, n, lv->coords, pi->new_vals, m->row_first);
+    input_rowof_kernel<<<nb, T, 0, st>>>(pi->slot_of, pi->new_vals, n, m->input_row, m->row_last, m->row_count);
+    SEI_LAUNCH_CHECK();
+    // the table maps key -> row from here on (a strided level begun behind this one probes nothing of it, but reads coords)
+    pool_free(lv->ht.vals);
+    lv->ht.vals = pi->new_vals;
+    pi->new_vals = nullptr;
+    lv->n_dev = pi->err_total + 1;
+    lv->n_ub = n;
+    lv->n = -1;
+    pi->pending = true;
+    return 0;
+}
+
+int build_input_level_finish(sei_metadata *m, PendingInput *pi, hipStream_t st, int64_t *n_rows) {
+    Level *lv = pi->level;
+    if (!pi->pending) {   // empty input
+        *n_rows = lv ? lv->n : 0;
+        return 0;
     }
-    if (host[2] != -1) {
-        pool_free(slot_of); pool_free(flag); pool_free(err_total); pool_free(new_vals);
-        SEI_FAIL("InputLayer: hash table full");
-    }
-    int64_t nr = host[1];
+    const int64_t n = pi->n;
+    const int32_t *host = reinterpret_cast<const int32_t *>(pi->host);
+    const int32_t bad = host[0], full = host[2];
+    const int64_t nr = host[1];
     lv->n = nr;
-    SEI_TRY(pool_alloc_t(&lv->coords, 4 * nr, st));
-    SEI_TRY(pool_alloc_t(&m->row_first, nr, st));
-    SEI_TRY(pool_alloc_t(&m->row_last, nr, st));
-    SEI_TRY(pool_alloc_t(&m->row_count, nr, st));
-    SEI_HIP(hipMemsetAsync(m->row_last, 0xFF, nr * sizeof(int32_t), st));
-    SEI_HIP(hipMemsetAsync(m->row_count, 0, nr * sizeof(int32_t), st));
-    assign_rows_kernel<<<nb, T, 0, st>>>(coords, slot_of, lv->ht.vals, flag, n, lv->coords, new_vals, m->row_first);
-    input_rowof_kernel<<<nb, T, 0, st>>>(slot_of, new_vals, n, m->input_row, m->row_last, m->row_count);
-    SEI_LAUNCH_CHECK();
-    if (nr != n) {
+    lv->n_dev = nullptr;
+    stage_put(pi->host);
+    pi->host = nullptr;
+    pi->pending = false;
+    int rc = 0;
+    if (bad != -1) {
+        set_error("InputLayer: coordinate of input point " + std::to_string((uint32_t)bad) + " is outside spatial_size / batch_size");
+        rc = 1;
+    } else if (full != -1) {
+        set_error("InputLayer: hash table full");
+        rc = 1;
+    }
+    if (!rc && nr != n) {
         // Several input points share a site (modes 3 / 4 sum them): their contributions are added in INPUT ORDER, not by
         // float atomics.  dup_order = the point indices sorted by row with a STABLE radix sort (equal rows keep their input
         // order), dup_start = exclusive scan of the rows' point counts: row r owns dup_order[dup_start[r] .. +row_count[r]).
         // Batches without duplicates (every DUNE / SBND input) skip all of this.
-        int32_t *keys_in = m->input_row, *keys_out, *idx_in;
-        SEI_TRY(pool_alloc_t(&keys_out, n, st));
-        SEI_TRY(pool_alloc_t(&idx_in, n, st));
-        SEI_TRY(pool_alloc_t(&m->dup_order, n, st));
-        SEI_TRY(pool_alloc_t(&m->dup_start, nr + 1, st));
-        iota_kernel<<<nb, T, 0, st>>>(idx_in, n);
-        int bits = 1;
-        while ((1ll << bits) < nr + 1 && bits < 31) bits++;
-        size_t tmp_bytes = 0;
-        SEI_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys_in, keys_out, idx_in, m->dup_order, (int)n, 0, bits, st));
-        void *tmp = pool_alloc(tmp_bytes + 256, st);
-        if (!tmp) SEI_FAIL("device pool: out of memory");
-        SEI_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys_in, keys_out, idx_in, m->dup_order, (int)n, 0, bits, st));
-        SEI_TRY(exclusive_scan_i32(m->row_count, m->dup_start, nr, nullptr, st));
-        pool_free(tmp); pool_free(keys_out); pool_free(idx_in);
+        const int T = 256;
+        const int nb = (int)((n + T - 1) / T);
+        int32_t *keys_in = m->input_row, *keys_out = nullptr, *idx_in = nullptr;
+        rc = pool_alloc_t(&keys_out, n, st);
+        if (!rc) rc = pool_alloc_t(&idx_in, n, st);
+        if (!rc) rc = pool_alloc_t(&m->dup_order, n, st);
+        if (!rc) rc = pool_alloc_t(&m->dup_start, nr + 1, st);
+        if (!rc) {
+            iota_kernel<<<nb, T, 0, st>>>(idx_in, n);
+            int bits = 1;
+            while ((1ll << bits) < nr + 1 && bits < 31) bits++;
+            size_t tmp_bytes = 0;
+            hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys_in, keys_out, idx_in, m->dup_order, (int)n, 0, bits, st);
+            void *tmp = e == hipSuccess ? pool_alloc(tmp_bytes + 256, st) : nullptr;
+            if (e == hipSuccess && tmp)
+                e = hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys_in, keys_out, idx_in, m->dup_order, (int)n, 0, bits, st);
+            if (e != hipSuccess || !tmp) { set_error("InputLayer: sorting the duplicate points failed"); rc = 1; }
+            if (!rc) rc = exclusive_scan_i32(m->row_count, m->dup_start, nr, nullptr, st);
+            pool_free(tmp);
+        }
+        pool_free(keys_out); pool_free(idx_in);
     }
-    // the table now maps key -> row
-    pool_free(lv->ht.vals);
-    lv->ht.vals = new_vals;
-    pool_free(slot_of);
-    pool_free(flag);
-    pool_free(err_total);
+    pool_free(pi->slot_of); pool_free(pi->flag); pool_free(pi->err_total);
+    pi->slot_of = nullptr; pi->flag = nullptr; pi->err_total = nullptr;
     *n_rows = nr;
-    return 0;
+    return rc;
+}
+
+int build_input_level(sei_metadata *m, const int32_t *coords, int64_t n, const int32_t spatial[3], int32_t batch,
+                      hipStream_t st, int64_t *n_rows) {
+    PendingInput pi;
+    int rc = build_input_level_begin(m, coords, n, spatial, batch, st, &pi);
+    if (!rc && pi.pending && sync_stream(st) != hipSuccess) {
+        set_error("InputLayer: hipStreamSynchronize failed");
+        rc = 1;
+    }
+    if (rc) {   // what begin allocated goes back; the level and the arrays the metadata owns are freed with the metadata
+        pool_free(pi.slot_of); pool_free(pi.flag); pool_free(pi.err_total); pool_free(pi.new_vals); stage_put(pi.host);
+        return rc;
+    }
+    return build_input_level_finish(m, &pi, st, n_rows);
 }
 
 // ------------------------------------------------------------------ InputLayer features

@@ -217,7 +217,7 @@ namespace {
 std::mutex g_stage_mu;
 std::vector<unsigned long long *> g_stage_free;
 }  // namespace
-static unsigned long long *stage_get() {
+unsigned long long *stage_get() {
     std::lock_guard<std::mutex> lk(g_stage_mu);
     if (!g_stage_free.empty()) {
         unsigned long long *p = g_stage_free.back();
@@ -231,7 +231,7 @@ static unsigned long long *stage_get() {
     }
     return (unsigned long long *)p;
 }
-static void stage_put(unsigned long long *p) {
+void stage_put(unsigned long long *p) {
     if (!p) return;
     std::lock_guard<std::mutex> lk(g_stage_mu);
     g_stage_free.push_back(p);
@@ -452,11 +452,18 @@ __device__ inline bool candidate(int4 p, int j, const ProbeGeom &g, int o0, int 
     return *q0 <= h0 && *q1 <= h1 && *q2 <= h2;
 }
 
-__global__ void out_insert_kernel(const int32_t *__restrict__ in_coords, int64_t n, int mult, int m1, int m2,
-                                  ProbeGeom g, int o0, int o1, int o2, uint64_t *keys, uint32_t *vals, uint64_t mask,
-                                  uint32_t *filter, uint64_t fmask, uint32_t *slot_of, int32_t *err) {
+// `n_dev` (optional): the row count of the input level as a DEVICE value -- the output-site count of the strided level in
+// front of this one when a chain of levels is discovered without a host read-back in between (`n` is then an upper bound that
+// sized the grid and the arrays)
+__global__ void out_insert_kernel(const int32_t *__restrict__ in_coords, int64_t n, const int32_t *__restrict__ n_dev, int mult,
+                                  int m1, int m2, ProbeGeom g, int o0, int o1, int o2, uint64_t *keys, uint32_t *vals,
+                                  uint64_t mask, uint32_t *filter, uint64_t fmask, uint32_t *slot_of, int32_t *err) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n * mult) return;
+    if (n_dev && t >= (int64_t)*n_dev * mult) {   // beyond the real rows: no candidate
+        slot_of[t] = 0xFFFFFFFFu;
+        return;
+    }
     int64_t i = t / mult;
     int j = (int)(t - i * mult);
     int4 p = reinterpret_cast<const int4 *>(in_coords)[i];
@@ -483,7 +490,7 @@ __global__ void out_assign_kernel(const int32_t *__restrict__ in_coords, int64_t
                                   ProbeGeom g, int o0, int o1, int o2, const uint32_t *slot_of, const uint32_t *vals,
                                   const int32_t *pos, int32_t *out_coords, uint32_t *new_vals) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n * mult) return;
+    if (t >= n * mult) return;   // candidates beyond the real rows carry slot_of = ~0 (out_insert_kernel) and fall out below
     uint32_t s = slot_of[t];
     if (s == 0xFFFFFFFFu || vals[s] != (uint32_t)t) return;
     int64_t i = t / mult;
@@ -502,9 +509,17 @@ Level *find_level(sei_metadata *m, const int32_t spatial[3]) {
     return nullptr;
 }
 
-// Discovers the output active set of a strided convolution and registers it as a new level.
-int build_strided_level(sei_metadata *m, Level *lin, const int32_t size[3], const int32_t stride[3], sei_rulebook *rb,
-                        hipStream_t st) {
+// Discovers the output active set of a strided convolution and registers it as a new level -- in two halves around the ONE
+// device -> host read-back of the site count:
+//   begin : tables and arrays sized for an UPPER BOUND of the input rows (every input row yields at most `mult` candidates),
+//           candidates inserted, first-child order by a scan, coordinates assigned; the count stays on the device.  If the
+//           input level was itself begun and not finished (`lin->n_dev`), its kernels' row count is read from the device: a
+//           CHAIN of levels is discovered back to back with no host synchronisation in between
+//           (sei_metadata_prebuild_like: one read-back for all strided levels of a batch instead of one per level).
+//   finish: after the stream has been synchronised past the begin's read-back: the count becomes the level's host row count.
+// The site set, the row order and therefore every rule list are the same whatever the table capacity was.
+int build_strided_level_begin(sei_metadata *m, Level *lin, const int32_t size[3], const int32_t stride[3], sei_rulebook *rb,
+                              hipStream_t st, PendingLevel *pl) {
     int32_t osz[3];
     for (int d = 0; d < 3; d++) {
         if (size[d] < 1 || stride[d] < 1) SEI_FAIL("Convolution: bad filter size / stride");
@@ -516,51 +531,97 @@ int build_strided_level(sei_metadata *m, Level *lin, const int32_t size[3], cons
     int m0 = (size[0] + stride[0] - 1) / stride[0], m1 = (size[1] + stride[1] - 1) / stride[1],
         m2 = (size[2] + stride[2] - 1) / stride[2];
     int mult = m0 * m1 * m2;
-    int64_t n = lin->n;
+    const int64_t n = lin->n_dev ? lin->n_ub : lin->n;   // rows of the input level, or their upper bound
     ProbeGeom g{1, size[0], size[1], size[2], stride[0], stride[1], stride[2], lin->spatial[0], lin->spatial[1],
                 lin->spatial[2]};
     ProfScope ps(PROF_RULES, st, 0.0, 12.0 * n * mult);
     Level *lo = new Level();
     for (int d = 0; d < 3; d++) lo->spatial[d] = osz[d];
     int64_t cand = n * mult;
-    if (cand >= (1ll << 31) - 64) SEI_FAIL("Convolution: too many candidate output sites");
-    SEI_TRY(alloc_table(&lo->ht, cand, st));
-    if (n == 0) {
+    if (cand >= (1ll << 31) - 64) { delete lo; SEI_FAIL("Convolution: too many candidate output sites"); }
+    int rc = alloc_table(&lo->ht, cand, st);
+    *pl = PendingLevel();
+    pl->level = lo;
+    if (!rc && n == 0) {
         lo->n = 0;
-        SEI_TRY(pool_alloc_t(&lo->coords, 4, st));
-    } else {
-        uint32_t *slot_of, *new_vals;
-        int32_t *flag, *total;
-        SEI_TRY(pool_alloc_t(&slot_of, cand, st));
-        SEI_TRY(pool_alloc_t(&flag, cand, st));
-        SEI_TRY(pool_alloc_t(&total, 2, st));  // [0] number of output sites, [1] table-full flag
-        SEI_HIP(hipMemsetAsync(total, 0, 2 * sizeof(int32_t), st));
-        SEI_TRY(pool_alloc_t(&new_vals, lo->ht.mask + 1, st));
-        SEI_HIP(hipMemsetAsync(new_vals, 0xFF, (lo->ht.mask + 1) * sizeof(uint32_t), st));
-        unsigned nb = (unsigned)((cand + 255) / 256);
-        out_insert_kernel<<<nb, 256, 0, st>>>(lin->coords, n, mult, m1, m2, g, osz[0], osz[1], osz[2], lo->ht.keys,
-                                              lo->ht.vals, lo->ht.mask, lo->ht.filter, lo->ht.fmask, slot_of, total + 1);
-        out_flag_kernel<<<nb, 256, 0, st>>>(slot_of, lo->ht.vals, cand, flag);
-        SEI_LAUNCH_CHECK();
-        SEI_TRY(exclusive_scan_i32(flag, flag, cand, total, st));
-        int32_t host2[2];
-        SEI_HIP(hipMemcpyAsync(host2, total, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-        SEI_HIP(sync_stream(st));
-        if (host2[1]) SEI_FAIL("Convolution: hash table full");
-        const int32_t host = host2[0];
-        lo->n = host;
-        SEI_TRY(pool_alloc_t(&lo->coords, 4 * (int64_t)(host > 0 ? host : 1), st));
-        out_assign_kernel<<<nb, 256, 0, st>>>(lin->coords, n, mult, m1, m2, g, osz[0], osz[1], osz[2], slot_of,
-                                              lo->ht.vals, flag, lo->coords, new_vals);
-        SEI_LAUNCH_CHECK();
-        pool_free(lo->ht.vals);
-        lo->ht.vals = new_vals;
-        pool_free(slot_of); pool_free(flag); pool_free(total);
+        rc = pool_alloc_t(&lo->coords, 4, st);
+    } else if (!rc) {
+        uint32_t *slot_of = nullptr, *new_vals = nullptr;
+        int32_t *flag = nullptr;
+        rc = pool_alloc_t(&slot_of, cand, st);
+        if (!rc) rc = pool_alloc_t(&flag, cand, st);
+        if (!rc) rc = pool_alloc_t(&pl->total, 2, st);  // [0] number of output sites, [1] table-full flag
+        if (!rc) rc = pool_alloc_t(&new_vals, lo->ht.mask + 1, st);
+        if (!rc) rc = pool_alloc_t(&lo->coords, 4 * (cand > 0 ? cand : 1), st);   // <= cand output sites
+        if (!rc) {
+            pl->host = stage_get();
+            if (!pl->host) { set_error("rulebook: cannot allocate pinned staging memory"); rc = 1; }
+        }
+        if (!rc) {
+            hipError_t e = hipMemsetAsync(pl->total, 0, 2 * sizeof(int32_t), st);
+            if (e == hipSuccess) e = hipMemsetAsync(new_vals, 0xFF, (lo->ht.mask + 1) * sizeof(uint32_t), st);
+            if (e != hipSuccess) { set_error(std::string("hipMemsetAsync: ") + hipGetErrorString(e)); rc = 1; }
+        }
+        if (!rc) {
+            unsigned nb = (unsigned)((cand + 255) / 256);
+            out_insert_kernel<<<nb, 256, 0, st>>>(lin->coords, n, lin->n_dev, mult, m1, m2, g, osz[0], osz[1], osz[2], lo->ht.keys,
+                                                  lo->ht.vals, lo->ht.mask, lo->ht.filter, lo->ht.fmask, slot_of, pl->total + 1);
+            out_flag_kernel<<<nb, 256, 0, st>>>(slot_of, lo->ht.vals, cand, flag);
+            rc = exclusive_scan_i32(flag, flag, cand, pl->total, st);
+            if (!rc) {
+                out_assign_kernel<<<nb, 256, 0, st>>>(lin->coords, n, mult, m1, m2, g, osz[0], osz[1], osz[2], slot_of,
+                                                      lo->ht.vals, flag, lo->coords, new_vals);
+                if (hipGetLastError() != hipSuccess) { set_error("rulebook: launch failed (strided level)"); rc = 1; }
+            }
+            if (!rc && hipMemcpyAsync(pl->host, pl->total, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st) != hipSuccess) {
+                set_error("rulebook: read-back of the site count failed"); rc = 1;
+            }
+        }
+        pool_free(slot_of); pool_free(flag);
+        if (!rc) {
+            pool_free(lo->ht.vals);
+            lo->ht.vals = new_vals;
+            lo->n_dev = pl->total;   // a level begun behind this one reads its row count from here
+            lo->n_ub = cand;
+            lo->n = -1;              // unknown on the host until build_strided_level_finish
+            pl->pending = true;
+        } else {
+            pool_free(new_vals);
+        }
+    }
+    if (rc) {
+        pool_free(lo->coords); pool_free(lo->ht.keys); pool_free(lo->ht.vals); pool_free(lo->ht.filter);
+        pool_free(pl->total); stage_put(pl->host);
+        delete lo;
+        *pl = PendingLevel();
+        return rc;
     }
     m->levels.push_back(lo);
     rb->lin = lin;
     rb->lout = lo;
     return 0;
+}
+
+int build_strided_level_finish(PendingLevel *pl) {
+    if (!pl->pending) return 0;
+    Level *lo = pl->level;
+    const int32_t *h = reinterpret_cast<const int32_t *>(pl->host);
+    const int32_t total = h[0], full = h[1];
+    lo->n = total;
+    lo->n_dev = nullptr;
+    pool_free(pl->total);
+    stage_put(pl->host);
+    pl->total = nullptr; pl->host = nullptr; pl->pending = false;
+    if (full) SEI_FAIL("Convolution: hash table full");
+    return 0;
+}
+
+int build_strided_level(sei_metadata *m, Level *lin, const int32_t size[3], const int32_t stride[3], sei_rulebook *rb,
+                        hipStream_t st) {
+    PendingLevel pl;
+    SEI_TRY(build_strided_level_begin(m, lin, size, stride, rb, st, &pl));
+    if (pl.pending && sync_stream(st) != hipSuccess) SEI_FAIL("rulebook: hipStreamSynchronize failed");
+    return build_strided_level_finish(&pl);
 }
 
 // ------------------------------------------------------------------ export as k-major lists (tests / inspection)

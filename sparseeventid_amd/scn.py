@@ -661,6 +661,10 @@ class InputLayer(nn.Module):
         self.spatial_size = torch.LongTensor(_triple(spatial_size))
         self.mode = mode
         self.device = None
+        # Metadata of an EARLIER batch through the same network (set by a training loop, e.g. Trainer): the strided levels
+        # it holds are discovered together with the input level (sei_input_build_like: ONE count read-back for the
+        # InputLayer and all levels instead of one each).  None: the plain InputLayer.
+        self.template = None
 
     def forward(self, input):
         if isinstance(input, SparseConvNetTensor):
@@ -688,8 +692,13 @@ class InputLayer(nn.Module):
         md = Metadata()
         sp = _triple(self.spatial_size)
         n_rows = ctypes.c_int64()
-        check(lib().sei_input_build(md.handle, _ptr(c32), c32.shape[0], i32x3(sp), batch_size, self.mode, _stream(),
-                                    ctypes.byref(n_rows)))
+        like = self.template
+        if like is not None and like.handle is not None:
+            check(lib().sei_input_build_like(md.handle, _ptr(c32), c32.shape[0], i32x3(sp), batch_size, self.mode,
+                                             like.handle, _stream(), ctypes.byref(n_rows)))
+        else:
+            check(lib().sei_input_build(md.handle, _ptr(c32), c32.shape[0], i32x3(sp), batch_size, self.mode, _stream(),
+                                        ctypes.byref(n_rows)))
         out = SparseConvNetTensor(metadata=md, spatial_size=self.spatial_size)
         out.features = _InputFeatures.apply(feats, md, n_rows.value)
         return out

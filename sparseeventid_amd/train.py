@@ -146,7 +146,9 @@ class Trainer:
             self._side.wait_event(after)
         inputs = tuple(x for x in image[:2] if isinstance(x, torch.Tensor) and x.is_cuda)
         with torch.cuda.stream(self._side):
-            t = (self.encoder.input_tensor if self.model == "sbnd" else self.encoder.input_layer)(image)
+            layer = self.encoder.input_tensor if self.model == "sbnd" else self.encoder.input_layer
+            layer.template = self._template if self.batch_rulebooks else None   # input level + strided levels: one read-back
+            t = layer(image)
             for x in inputs:
                 x.record_stream(self._side)   # read by the side stream's kernels: not reusable before they are done
             try:
@@ -168,6 +170,9 @@ class Trainer:
             image.tensor.features.record_stream(main)   # allocated on the side stream, consumed here
             image = image.tensor
         else:
+            # with the previous batch's metadata as the template the InputLayer discovers the strided levels together with
+            # the input level (scn.InputLayer.template -> sei_input_build_like: ONE count read-back for all of them)
+            layer.template = self._template if self.batch_rulebooks else None
             image = layer(image)     # Encoder.forward / ResNet.forward pass a prepared tensor through
             if self.batch_rulebooks and self._template is not None and image.features.is_cuda:
                 # every rulebook (forward AND backward variants) the previous batch needed, built now with ONE count

@@ -203,8 +203,9 @@ def _sync_count(reset=False):
 def test_batched_rulebook_build_needs_one_readback_and_changes_nothing():
     """From the second step on the Trainer builds every rulebook variant of the batch -- forward, transposed and dW's --
     at the top of the forward pass from the previous batch's list (sei_metadata_prebuild_like on the main stream): ONE
-    count read-back for all of them, plus one for the InputLayer and one per strided level, and none in the backward
-    pass; the lazy path synchronises once per variant.  Training is bit-identical either way."""
+    count read-back for all of them, plus ONE for the InputLayer and all strided levels together (round 4: they are
+    discovered as a chain whose row counts stay on the device), and none in the backward pass; the lazy path
+    synchronises once per level and per variant.  Training is bit-identical either way."""
     lazy, batched = _trainer(), _trainer()
     lazy.batch_rulebooks = False
     data = _batches(lazy)
@@ -219,10 +220,11 @@ def test_batched_rulebook_build_needs_one_readback_and_changes_nothing():
             torch.cuda.synchronize()
             counts[name].append(_sync_count())
     assert torch.equal(lazy.arena.flat, batched.arena.flat)
-    levels = 2                                   # depth-2 encoder: two strided convolutions
+    # ONE for the InputLayer and all strided levels (discovered as a chain with device-side row counts: scn.InputLayer.template
+    # -> sei_input_build_like), ONE for all tiled variants
     assert counts["batched"][0] == counts["lazy"][0]              # first step: nothing to copy the list from
-    assert all(c == 1 + levels + 1 for c in counts["batched"][1:]), counts
-    assert all(c > 1 + levels + 1 for c in counts["lazy"]), counts
+    assert all(c == 2 for c in counts["batched"][1:]), counts
+    assert all(c > 3 for c in counts["lazy"]), counts
 
 
 def test_forward_only_prebuild_skips_the_backward_variants():
@@ -289,8 +291,7 @@ def test_eval_step_between_training_steps_keeps_the_training_template():
         out[name] = (logits, n_eval, _sync_count())
     for k in out["lazy"][0]:
         assert torch.equal(out["lazy"][0][k], out["batched"][0][k]), k
-    levels = 2
-    assert out["batched"][1] == 1 + levels + 1 and out["batched"][2] == 1 + levels + 1, out["batched"][1:]
+    assert out["batched"][1] == 2 and out["batched"][2] == 2, out["batched"][1:]
     assert torch.equal(lazy.arena.flat, batched.arena.flat)
 
 
@@ -410,3 +411,58 @@ def test_lazy_build_waits_for_a_batch_build_in_flight():
         if want is None:
             want = used
         assert used <= want + (1 << 20), (it, used, want)   # nothing accumulates from one round to the next
+
+
+def test_input_layer_with_a_template_discovers_the_levels_in_one_readback():
+    """scn.InputLayer.template (sei_input_build_like): the input level and the chain of strided levels the template holds
+    are discovered back to back with their row counts on the device -- ONE stream synchronisation -- and are the SAME levels
+    the lazy path finds one read-back at a time: rows, coordinates and the rulebooks cut from them; duplicate input points
+    (summed in input order) and an out-of-range coordinate behave as without a template."""
+    import sparseeventid_amd.scn as scn
+    sp = [40, 36, 44]
+
+    def net(t):   # three levels deep; returns row counts, level coordinates and rule counts
+        out = []
+        f = torch.ones(t.features.shape[0], 16, device="cuda")
+        t = scn.SparseConvNetTensor(f, t.metadata, t.spatial_size)
+        for _ in range(3):
+            s3 = [int(v) for v in t.spatial_size]
+            rb = t.metadata.subm_rulebook(s3, [3, 3, 3])
+            out.append((t.features.shape[0], rb.stats(128)[:3], t.metadata.coords(s3, "cuda").cpu().clone()))
+            conv = scn.Convolution(3, 16, 16, 2, 2, False).cuda()
+            with torch.no_grad():
+                t = conv(t)
+        out.append((t.features.shape[0],))
+        return out
+
+    layer = scn.InputLayer(3, sp)
+    ca, fa = blob_cloud(3, 2, sp, 1500, 2)
+    ta = layer((torch.from_numpy(ca), torch.from_numpy(fa).cuda(), 2))
+    net(ta)                                                      # the template: three strided levels
+    rng = np.random.default_rng(5)
+    cb, fb = blob_cloud(4, 3, sp, 1100, 2)
+    dup = rng.integers(0, len(cb), 400)                         # duplicate points: modes 3 sums them in input order
+    cb = np.concatenate([cb, cb[dup]]); fb = np.concatenate([fb, rng.standard_normal((400, 2)).astype(np.float32)])
+    plain = layer((torch.from_numpy(cb), torch.from_numpy(fb).cuda(), 3))
+    want = net(plain)
+    torch.cuda.synchronize()
+    tl = scn.InputLayer(3, sp)
+    tl.template = ta.metadata
+    _sync_count(reset=True)
+    fast = tl((torch.from_numpy(cb), torch.from_numpy(fb).cuda(), 3))
+    torch.cuda.synchronize()
+    assert _sync_count() == 1
+    assert torch.equal(fast.features, plain.features)
+    _sync_count(reset=True)
+    got = net(fast)
+    for a, b in zip(want, got):
+        assert a[0] == b[0]
+        if len(a) > 1:
+            assert a[1] == b[1] and torch.equal(a[2], b[2])
+    # an out-of-range coordinate is reported, not swallowed by the level chain behind it
+    bad = cb.copy(); bad[7, 1] = sp[1] + 3
+    with pytest.raises(RuntimeError, match="outside spatial_size"):
+        tl((torch.from_numpy(bad), torch.from_numpy(fb).cuda(), 3))
+    # and an empty batch goes through
+    e = tl((torch.zeros(0, 4), torch.zeros(0, 2).cuda(), 2))
+    assert e.features.shape[0] == 0
