@@ -79,10 +79,39 @@ __global__ void scan_apply_kernel(const int32_t *in, int32_t *out, int64_t n, co
     }
 }
 
+// short arrays (the per-tile sub-chunk counts of a tiled rulebook variant: ~150 scans per training step, most of them of a
+// few thousand elements) in ONE launch of one workgroup instead of three launches: every thread scans a contiguous run
+constexpr int SCAN_SMALL_THREADS = 1024, SCAN_SMALL_MAX = SCAN_SMALL_THREADS * 32;
+__global__ __launch_bounds__(SCAN_SMALL_THREADS) void scan_small_kernel(const int32_t *in, int32_t *out, int n, int32_t *total_out) {
+    __shared__ int lds[SCAN_SMALL_THREADS / 64 + 1];
+    const int per = (n + SCAN_SMALL_THREADS - 1) / SCAN_SMALL_THREADS;   // <= 32
+    const int b = threadIdx.x * per, e = min(n, b + per);
+    int v[32];
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < 32; i++) {
+        v[i] = (i < per && b + i < e) ? in[b + i] : 0;
+        s += v[i];
+    }
+    int tot;
+    int ex = block_exclusive_scan(s, &tot, lds);
+#pragma unroll
+    for (int i = 0; i < 32; i++) {
+        if (i < per && b + i < e) out[b + i] = ex;
+        ex += v[i];
+    }
+    if (threadIdx.x == 0 && total_out) *total_out = tot;
+}
+
 // out[i] = sum_{j<i} in[j]; *total_dev (device int, may be null) = sum of all.  in/out may alias.
 int exclusive_scan_i32(const int32_t *in, int32_t *out, int64_t n, int32_t *total_dev, hipStream_t st) {
     if (n == 0) {
         if (total_dev) SEI_HIP(hipMemsetAsync(total_dev, 0, sizeof(int32_t), st));
+        return 0;
+    }
+    if (n <= SCAN_SMALL_MAX) {
+        scan_small_kernel<<<1, SCAN_SMALL_THREADS, 0, st>>>(in, out, (int)n, total_dev);
+        SEI_LAUNCH_CHECK();
         return 0;
     }
     int nb = (int)((n + SCAN_BLOCK - 1) / SCAN_BLOCK);
