@@ -16,7 +16,7 @@ echo "serial: $(python3 -c "import json;d=json.load(open('gpurun_out/$R/${R}_ben
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/prof -- python3 bench.py --steps 5 --warmup 2 --cpu-events 0 --overlap-backward 0 --no-prefetch > gpurun_out/$R/prof_serial.log 2>&1
 f=$(find gpurun_out/$R/prof -name "*kernel_stats.csv" | head -1); cp "$f" gpurun_out/$R/${R}_bench_serial_kernel_stats.csv 2>/dev/null; rm -rf gpurun_out/$R/prof
 export SEI_GEN_WORKERS=1
-bash tools/traffic.sh > gpurun_out/$R/traffic.log 2>&1; cp gpurun_out/$R_conv_fwd_hbm_traffic.json gpurun_out/$R/ 2>/dev/null
+bash tools/traffic.sh > gpurun_out/$R/traffic.log 2>&1; cp gpurun_out/${R}_conv_fwd_hbm_traffic.json gpurun_out/$R/ 2>/dev/null
 echo "traffic: $(python3 -c "import json;d=json.load(open('gpurun_out/$R/${R}_conv_fwd_hbm_traffic.json'));print(d['traffic_bytes_per_launch'], d['launches'])")"
 rm -rf gpurun_out/$R/pmc
 timeout -k 10 500 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d gpurun_out/$R/pmc -- python3 bench.py --steps 1 --warmup 1 --cpu-events 0 --no-prof > gpurun_out/$R/pmc.log 2>&1
