@@ -339,3 +339,49 @@ def test_metadata_destroyed_while_its_kernels_are_queued():
     torch.cuda.synchronize()
     for i, y in outs:
         assert torch.equal(y, want[i]), i
+
+
+def test_metadata_destroyed_beside_allocations_of_another_thread():
+    """sei_metadata_destroy quarantines its blocks behind a fence and adds them to it block by block, dropping the pool's
+    mutex in between; a pool_alloc of ANOTHER thread in that window reaps fences whose events have completed.  The fence
+    carries an owner reference until pool_fence_end, so the reap can no longer delete it under the destroy loop (round-3
+    advisor finding: a double delete / lost events).  Two host threads build and destroy metadata on their own streams."""
+    import ctypes
+    import threading
+    import sparseeventid_amd.scn as scn
+    from sparseeventid_amd._lib import lib
+    sp = [24, 26, 22]
+    clouds = [blob_cloud(60 + i, 2, sp, 500 + 40 * i, 1) for i in range(4)]
+    errs = []
+
+    def used():
+        held, in_use = ctypes.c_int64(), ctypes.c_int64()
+        assert lib().sei_pool_stats(ctypes.byref(held), ctypes.byref(in_use)) == 0
+        return in_use.value
+
+    torch.cuda.synchronize()
+    base = used()
+
+    def worker(seed):
+        try:
+            st = torch.cuda.Stream()
+            layer = scn.InputLayer(3, sp)
+            with torch.cuda.stream(st):
+                for it in range(40):
+                    c, f = clouds[(seed + it) % len(clouds)]
+                    t = layer((torch.from_numpy(c), torch.from_numpy(f).cuda(), 2))
+                    rb = t.metadata.subm_rulebook(sp, [3, 3, 3])
+                    rb.stats(64 if it % 2 else 128)
+                    del rb, t                      # destroys the metadata: fenced frees of ~10 blocks
+        except Exception as e:   # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t_ in th:
+        t_.start()
+    for t_ in th:
+        t_.join(120)
+        assert not t_.is_alive()
+    torch.cuda.synchronize()
+    assert not errs, errs
+    assert used() == base
