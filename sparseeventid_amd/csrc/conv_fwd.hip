@@ -182,21 +182,8 @@ constexpr int APAD = 0;  // the shared tile helpers (conv_tile.h) assume an unpa
 // 6 waves per SIMD = 80 registers there instead of landing on the step by luck.
 constexpr int occ8_for(int nt, int cs, int slj, int maxs) {
     const int cout = 16 * nt * cs, tr = 16 * maxs * (8 / cs);
-    // (a FOURTH workgroup fits the 128-column layers' LDS once the segment table is out of it, but needs 64 registers: 76 B of
-    // scratch, 81.0 vs 85.8 TFLOP/s -- profiles/r04_conv_tile_experiments.log)
     return 3 * (tr * cout + 2 * 16 * slj * cout) * 4 + 3 * 128 <= 160 * 1024 ? 6 : 4;
 }
-
-// The tile's segment table (K + 1 words: where each offset's sub-chunks begin) lives in a LANE REGISTER of every wave when it
-// fits (K + 1 <= 64: seg_in_reg), read back with v_readlane, and the non-empty offsets are a 64-bit mask: finding the next
-// offset and its sub-chunk range -- done by every wave at every offset, in front of its index loads -- used to be a chain of
-// dependent LDS reads (a  while (seg[k + 1] == seg[k])  loop) and cost the kernels 4-5 % (round 4: 75.4 -> 78.6, 81.5 -> 85.8,
-// 80.0 -> 83.8 TFLOP/s at 96 / 128 / 160 planes).  Longer tables (a 5^3 filter has 126 words) stay in LDS.
-#ifdef SEI_TRACE
-__host__ __device__ constexpr bool seg_in_reg(int) { return false; }   // the trace build keeps its slot behind the LDS table
-#else
-__host__ __device__ constexpr bool seg_in_reg(int K) { return K + 1 <= 64; }
-#endif
 
 template <int NT, int CS, int SLJ, int MAXS, int NW = 4>
 __global__ __launch_bounds__(64 * NW, (NW == 8 ? occ8_for(NT, CS, SLJ, MAXS) : occ_for(MAXS, NT, SLJ))) void conv_tile_mfma_kernel(
@@ -231,13 +218,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? occ8_for(NT, CS, SLJ, MAXS) : o
 
     STAMP_DECL;
     TRACE_DECL;
-    // segment table: lane l of every wave holds seg[l] (seg_in_reg), else LDS
-    const bool SEGREG = seg_in_reg(K);   // wave-uniform
-    const int segv = (SEGREG && lane <= K) ? tile_seg[(size_t)tile * (K + 1) + lane] : 0;
-    const int seg_ns = __shfl_down(segv, 1) - segv;   // sub-chunks of offset `lane` (shuffled by ALL lanes: lane K must supply seg[K])
-    const unsigned long long kmask = SEGREG ? __ballot(lane < K && seg_ns > 0) : 0ull;
-    if (!SEGREG)
-        for (int i = threadIdx.x; i <= K; i += 64 * NW) seg[i] = tile_seg[(size_t)tile * (K + 1) + i];
+    for (int i = threadIdx.x; i <= K; i += 64 * NW) seg[i] = tile_seg[(size_t)tile * (K + 1) + i];
     tile_init<TR, COUT, 64 * NW>(acc_tile, bias, init, (int64_t)tile * TR, n_dst, ldy, ycol0);
     __syncthreads();
 
@@ -245,19 +226,14 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? occ8_for(NT, CS, SLJ, MAXS) : o
     const int NS = CIN / SL;  // slices per offset
 
     auto next_k = [&](int k) {  // next offset with rules in this tile (K if none)
-        if (SEGREG) {
-            const unsigned long long rem = k + 1 < 64 ? (kmask >> (k + 1)) << (k + 1) : 0ull;
-            return __builtin_amdgcn_readfirstlane(rem ? __ffsll((long long)rem) - 1 : K);
-        }
         if (k < K) k++;
         while (k < K && seg[k + 1] == seg[k]) k++;
         return __builtin_amdgcn_readfirstlane(k);
     };
-    auto seg_at = [&](int i) { return SEGREG ? __builtin_amdgcn_readlane(segv, __builtin_amdgcn_readfirstlane(i)) : seg[i]; };
     auto load_idx = [&](int k) {  // clamped: k == K re-reads the last offset's (unused) slots
         RuleIdx<MAXS> r;
         const int kk = k < K ? k : K - 1;
-        int s0 = __builtin_amdgcn_readfirstlane(seg_at(kk)), ns = __builtin_amdgcn_readfirstlane(seg_at(kk + 1)) - s0;
+        int s0 = __builtin_amdgcn_readfirstlane(seg[kk]), ns = __builtin_amdgcn_readfirstlane(seg[kk + 1]) - s0;
         if (k >= K) ns = 0;
         int ms = 0;
 #pragma unroll
@@ -569,7 +545,7 @@ __global__ void fill_bias_kernel(float *Y, int64_t n, int C, const float *bias) 
 }
 
 static size_t fwd_lds(int tile_rows, int nOut, int slj, int K) {
-    size_t b = ((size_t)tile_rows * (nOut + APAD) + 2 * 16 * slj * nOut) * sizeof(float) + (seg_in_reg(K) ? 0 : (K + 1) * sizeof(int));
+    size_t b = ((size_t)tile_rows * (nOut + APAD) + 2 * 16 * slj * nOut) * sizeof(float) + (K + 1) * sizeof(int);
 #ifdef SEI_TRACE
     b += 16;   // the trace slot of the workgroup
 #endif
