@@ -65,6 +65,6 @@ def test_sbnd_network_parity():
         if float(og.abs().max()) < 1e-5 * gmax:
             assert float(p.grad.abs().max()) < 1e-4 * gmax, k
             continue
-        assert rel_err(p.grad, og) < 2e-3, k
+        assert rel_err(p.grad, og) < 1e-4, k
     for k, b in net.named_buffers():
         assert rel_err(b, osd[k]) < 1e-4, k
