@@ -297,6 +297,7 @@ int forced_conv_kernel() {
         if (!strcmp(e, "tile")) return CONV_KERNEL_TILE;
         if (!strcmp(e, "wave")) return CONV_KERNEL_WAVE;
         if (!strcmp(e, "band")) return CONV_KERNEL_BAND;
+        if (!strcmp(e, "cols")) return CONV_KERNEL_COLS;
     }
 #endif
     return g_force_kernel.load(std::memory_order_relaxed);
@@ -717,7 +718,7 @@ static int conv_forward_impl(sei_rulebook_t *rb, const float *X, const float *W,
         bias = ab.p;
     }
     const int kind = nIn == 32 && nOut == 32 ? PROF_CONV_FWD_C32 : PROF_CONV_FWD;
-    if (p.kind != 1) {  // natural weight layout: no copy
+    if (p.kind != 1 && p.kind != 4) {  // natural weight layout: no copy
         if (p.kind >= 2) {
             SEI_TRY(aw.stage(W, (size_t)t->K * nIn * nOut, st));
             W = aw.p;
@@ -725,7 +726,8 @@ static int conv_forward_impl(sei_rulebook_t *rb, const float *X, const float *W,
         ProfScope ps(kind, st, 2.0 * t->n_rules * nIn * nOut, conv_bytes(*t, nIn, nOut));
         return conv_forward(*t, X, W, bias, Y, nIn, nOut, st, nullptr, stats, ep);
     }
-    // the workgroup-tile MFMA kernel reads B operands with wide LDS loads from column-permuted weights (tiny copy, <= 4 MB)
+    // the workgroup-tile MFMA kernel reads B operands with wide LDS loads from column-permuted weights (tiny copy, <= 4 MB);
+    // the column-owner kernel (kind 4, col_group -1) reads them from a copy packed per column tile
     float *Wp;
     SEI_TRY(pool_alloc_t(&Wp, (size_t)t->K * nIn * nOut, st));
     int rc = conv_transform_weights(W, Wp, t->K, nIn, nOut, false, false, p.col_group, p.blocks, st);
@@ -811,7 +813,7 @@ static int conv_backward_input_impl(sei_rulebook_t *rb, const float *dY, const f
     float *Wt;
     SEI_TRY(pool_alloc_t(&Wt, (size_t)t->K * nIn * nOut, st));
     // Wt[k'][co][ci] = W[K-1-k' (submanifold mirror) or k'][ci][co] (kind 1: columns (ci) permuted for the kernel)
-    int rc = conv_transform_weights(W, Wt, t->K, nIn, nOut, true, rb->submanifold, p.kind == 1 ? p.col_group : 0,
+    int rc = conv_transform_weights(W, Wt, t->K, nIn, nOut, true, rb->submanifold, (p.kind == 1 || p.kind == 4) ? p.col_group : 0,
                                     p.kind == 1 ? p.blocks : 1, st);
     if (!rc) {
         ProfScope ps(nIn == 32 && nOut == 32 ? PROF_CONV_BWD_IN_C32 : PROF_CONV_BWD_IN, st, 2.0 * t->n_rules * nIn * nOut,
@@ -924,7 +926,7 @@ int sei_debug_force_dw_kernel(int32_t kind) {
 }
 
 int sei_debug_force_conv_kernel(int32_t kind) {
-    if (kind < CONV_KERNEL_AUTO || kind > CONV_KERNEL_BAND) SEI_FAIL("sei_debug_force_conv_kernel: kind must be 0..3");
+    if (kind < CONV_KERNEL_AUTO || kind > CONV_KERNEL_COLS) SEI_FAIL("sei_debug_force_conv_kernel: kind must be 0..4");
 #ifndef SEI_EXPERIMENTS
     if (kind == CONV_KERNEL_BAND) SEI_FAIL("sei_debug_force_conv_kernel: the row-band kernels exist only in experiment builds (make EXTRA=-DSEI_EXPERIMENTS)");
 #endif

@@ -289,7 +289,8 @@ int export_rules(const TiledRules &t, int64_t *start_host, int32_t *rin, int32_t
 // transform and launch.
 struct ConvPlan {
     int kind = 0;        // 0 scalar tile kernels (tiny / odd plane counts), 1 workgroup-tile MFMA kernel, 2 wave-private MFMA kernel,
-                         // 3 row-band MFMA kernel (nw = compute waves per workgroup, g = ring depth in slices)
+                         // 3 row-band MFMA kernel (nw = compute waves per workgroup, g = ring depth in slices),
+                         // 4 column-owner MFMA kernel (conv_cols.hip; weights packed per column tile: col_group = -1)
     int tile_rows = 0;   // rulebook variant (dst rows per tile)
     int col_group = 0;   // kind 1: width of the column groups whose columns are stored permuted (0 = natural layout)
     int blocks = 1;      // column blocks (kind 1: weights stored as [block][K][nIn][nOut/blocks])
@@ -300,7 +301,7 @@ struct ConvPlan {
 ConvPlan plan_conv(int nIn, int nOut, int K, int64_t n_dst);
 // sei_debug_force_conv_kernel(): pins the forward / dX kernel family for every later call of the process
 // (bit-identity tests between the kernels, sweeps); AUTO = the plan picks
-enum { CONV_KERNEL_AUTO = 0, CONV_KERNEL_TILE = 1, CONV_KERNEL_WAVE = 2, CONV_KERNEL_BAND = 3 };
+enum { CONV_KERNEL_AUTO = 0, CONV_KERNEL_TILE = 1, CONV_KERNEL_WAVE = 2, CONV_KERNEL_BAND = 3, CONV_KERNEL_COLS = 4 };
 int forced_conv_kernel();
 // sei_debug_force_dw_kernel(): dW kernel family (AUTO = the library's choice)
 enum { DW_KERNEL_AUTO = 0, DW_KERNEL_REG = 1, DW_KERNEL_RING = 2 };
@@ -308,6 +309,7 @@ int forced_dw_kernel();
 int dw_ring_timeouts(int *out, bool reset);
 bool plan_wave(int nIn, int nOut, int K, int64_t n_dst, ConvPlan *p);
 bool plan_band(int nIn, int nOut, int K, int64_t n_dst, ConvPlan *p);
+bool plan_cols(int nIn, int nOut, int K, int64_t n_dst, ConvPlan *p);
 // stats (optional, MFMA kernels only): per-(tile, part) column sums of the OUTPUT rows, [n_parts][2][nOut] doubles
 // (sum, sum of squares) accumulated in the kernel epilogue from the LDS tile -- BatchNorm statistics without a second
 // read of the conv output.  conv_stats_parts() = how many parts this plan writes (0: the plan cannot).
@@ -342,6 +344,8 @@ int conv_forward_wave(const TiledRules &t, const ConvPlan &p, const float *X, co
                       const ConvEpilogue &ep = ConvEpilogue{});
 int conv_forward_band(const TiledRules &t, const ConvPlan &p, const float *X, const float *W, const float *bias, float *Y,
                       int nIn, int nOut, const float *init, double *stats, hipStream_t st);
+int conv_forward_cols(const TiledRules &t, const ConvPlan &p, const float *X, const float *Wp, const float *bias, float *Y,
+                      int nIn, int nOut, const float *init, double *stats, hipStream_t st, const ConvEpilogue &ep);
 int64_t conv_stats_parts(const ConvPlan &p, const TiledRules &t);
 // Wout[k][r][perm(c)]: transpose=false: rows=nIn, cols=nOut (forward); transpose=true: Wout[k][co][perm(ci)] = W[ks][ci][co]
 // with ks = flip ? K-1-k : k (dX).  perm = column permutation inside groups of `col_group` columns (0 = identity).

@@ -39,6 +39,10 @@ __device__ inline int permute_col(int c, int width) {
 // columns of every group permuted, or (blocks > 1) [block][K][rows][cols / blocks] so that each column block is
 // a contiguous panel for the workgroups that own it
 __device__ inline size_t weight_index(int ks, int row, int col, int K, int rows, int cols, int col_group, int blocks) {
+    if (col_group < 0) {  // column-owner kernel: [k][column tile][16-row group][lane = (row % 16) / 4 * 16 + col % 16][row % 4]
+        const int cb = col >> 4, j = row >> 4, ln = ((row & 15) >> 2) * 16 + (col & 15);
+        return ((((size_t)ks * (cols >> 4) + cb) * (rows >> 4) + j) * 64 + ln) * 4 + (row & 3);
+    }
     const int pc = permute_col(col, col_group);
     if (blocks <= 1) return ((size_t)ks * rows + row) * cols + pc;
     const int w = cols / blocks, b = pc / w;

@@ -645,6 +645,7 @@ static ConvPlan plan_tile(int nIn, int nOut, int K, int64_t n_dst) {
 ConvPlan plan_conv(int nIn, int nOut, int K, int64_t n_dst) {
     ConvPlan p{};
     if (plan_band(nIn, nOut, K, n_dst, &p)) return p;
+    if (plan_cols(nIn, nOut, K, n_dst, &p)) return p;
     if (plan_wave(nIn, nOut, K, n_dst, &p)) return p;
     return plan_tile(nIn, nOut, K, n_dst);
 }
@@ -693,6 +694,10 @@ int64_t conv_stats_parts(const ConvPlan &p, const TiledRules &t) {
         const int cout = p.nt * p.cs * 16;
         return (int64_t)t.n_tiles * (256 / cout > 0 ? 256 / cout : 1);
     }
+    if (p.kind == 4) {  // the workgroup-tile epilogue over all nw * 16 columns
+        const int cout = p.nw * 16;
+        return (int64_t)t.n_tiles * (256 / cout > 0 ? 256 / cout : 1);
+    }
     if (p.kind == 3 && p.cs) {  // shared-tile ring kernel: the workgroup-tile epilogue (conv_tile.h: tile_stats)
         const int cout = p.nt * 16;
         return (int64_t)t.n_tiles * (256 / cout > 0 ? 256 / cout : 1);
@@ -708,7 +713,7 @@ int64_t conv_stats_parts(const ConvPlan &p, const TiledRules &t) {
 bool conv_epilogue_supported(int nIn, int nOut, int K, int64_t n_dst, const TiledRules &t) {
     if (t.n_dst == 0 || t.n_sub == 0 || nOut % 4) return false;
     const ConvPlan p = plan_conv(nIn, nOut, K, n_dst);
-    if (p.kind == 1 || p.kind == 2) return true;
+    if (p.kind == 1 || p.kind == 2 || p.kind == 4) return true;
     if (p.kind != 0) return false;
     return nIn <= 4 && (nOut == 16 || nOut == 32 || nOut == 64) && t.K + 1 <= 128 && t.tile_rows % 4 == 0 &&
            ((size_t)t.tile_rows * nOut + (size_t)t.K * nIn * nOut) * sizeof(float) <= 160 * 1024;
@@ -732,6 +737,7 @@ int conv_forward(const TiledRules &t, const float *X, const float *W, const floa
     if (stats && (p.kind == 0 || t.n_sub == 0)) SEI_FAIL("conv_forward: statistics are only produced by the MFMA kernels");
     if (p.kind == 2) return conv_forward_wave(t, p, X, W, bias, Y, nIn, nOut, init, stats, st, epv);
     if (p.kind == 3) return conv_forward_band(t, p, X, W, bias, Y, nIn, nOut, init, stats, st);
+    if (p.kind == 4) return conv_forward_cols(t, p, X, W, bias, Y, nIn, nOut, init, stats, st, epv);
     if (p.kind == 1) {
         // eight-wave workgroups: 96 columns in one block, 128 / 160 (and 96 behind a 16-plane input) in two column blocks
         FWD_CASE8(3) FWD_CASE8(4) FWD_CASE8(5) FWD_CASE8S2(6)

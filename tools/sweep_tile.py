@@ -39,7 +39,8 @@ def main():
     R = rb.n_rules
     for rnd in range(a.rounds):        # plans interleaved over several rounds: clocks drift during a run
         for plan in a.plans:
-            if plan == "default":
+            os.environ["SEI_CONV_KERNEL"] = "cols" if plan == "cols" else "tile"   # "cols": the column-owner kernel (conv_cols.hip)
+            if plan in ("default", "cols"):
                 os.environ.pop("SEI_FWD_PLAN", None)
             else:
                 os.environ["SEI_FWD_PLAN"] = plan
