@@ -392,6 +392,151 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? occ8_for(NT, CS, SLJ, MAXS) : o
     TRACE_END;
 }
 
+// ------------------------------------------------------------------------------------------ two-offset rounds
+// The kernel above deals the sub-chunks of ONE offset to its eight waves per phase; a 128-row tile of the DUNE batch holds
+// ~4.4 of them per offset, so on average 3.6 waves idle at every phase barrier (profiles/r04_conv_tile_cu_timeline_*).
+// Here the tile's sub-chunks are walked as one stream in ROUNDS of up to NW consecutive sub-chunks that may span TWO
+// consecutive (nonempty) offsets a < b: wave w takes sub-chunk q0 + w and reads its B operands from the weight slice of the
+// offset that sub-chunk belongs to.  Both offsets' 16-plane slices are staged per phase (2 offsets x 2 buffers x 16 x COUT
+// floats: the LDS of one double-buffered 32-plane slice), a round is nIn / 16 phases, and a round that cannot be filled
+// from two offsets is cut short (never three: the LDS holds two).  The sums keep their order: a sub-chunk is still one
+// MFMA chain over the input planes added to the tile once, and inside a round the sub-chunks of a are added before those of
+// b (one extra barrier per round that holds both); rows of one offset are distinct, so results are bit-identical to the
+// kernel above.
+struct Round {
+    int q0, q1;   // tile-relative sub-chunks [q0, q1)
+    int a, b;     // their offsets: a for q < ea, b from ea on (b == a: a alone)
+    int ea;
+};
+
+template <int NT, int NW>
+__global__ __launch_bounds__(64 * NW, occ8_for(NT, 1, 2, 1)) void conv_round_mfma_kernel(
+    const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ Y,
+    const int32_t *__restrict__ tile_sub_start, const int32_t *__restrict__ tile_seg,
+    const int32_t *__restrict__ sub_src, const uint8_t *__restrict__ sub_dst, int64_t n_dst, int K, int CIN, int n_tiles,
+    const float *__restrict__ init, int ldy, int blocks, double *__restrict__ stats, ConvEpilogue ep) {
+    extern __shared__ float lds[];
+    constexpr int TR = 16 * NW, SL = 16, COUT = NT * 16, PIECES = SL * COUT / 256;
+    const int vid = xcd_item(n_tiles * blocks);
+    if (vid >= n_tiles * blocks) return;
+    const int tile = vid / blocks, cblk = vid - tile * blocks;
+    W += (size_t)cblk * K * CIN * COUT;
+    if (bias) bias += cblk * COUT;
+    const int ycol0 = cblk * COUT;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r16 = lane & 15, g = lane >> 4;
+    float *acc_tile = lds;
+    float *wbuf = lds + (size_t)TR * COUT;   // [buffer][offset half][SL][COUT]
+    int *seg = reinterpret_cast<int *>(wbuf + 4 * SL * COUT);
+
+    for (int i = threadIdx.x; i <= K; i += 64 * NW) seg[i] = tile_seg[(size_t)tile * (K + 1) + i];
+    tile_init<TR, COUT, 64 * NW>(acc_tile, bias, init, (int64_t)tile * TR, n_dst, ldy, ycol0);
+    __syncthreads();
+
+    const int64_t sub0 = tile_sub_start[tile];
+    const int NS = CIN / SL;
+    const int n = __builtin_amdgcn_readfirstlane(seg[K]);
+
+    auto plan = [&](int q0, int c) {  // the round starting at sub-chunk q0; c = an offset at or below the one holding q0
+        Round r;
+        r.q0 = q0;
+        if (q0 >= n) { r.q1 = q0; r.a = r.b = c < K ? c : K - 1; r.ea = q0; return r; }
+        while (__builtin_amdgcn_readfirstlane(seg[c + 1]) <= q0) c++;
+        r.a = c;
+        r.ea = __builtin_amdgcn_readfirstlane(seg[c + 1]);
+        r.b = c;
+        if (q0 + NW <= r.ea) { r.q1 = q0 + NW; return r; }
+        int b = c + 1;
+        while (b < K && __builtin_amdgcn_readfirstlane(seg[b + 1]) == r.ea) b++;   // empty offsets end where a ends
+        if (b >= K) { r.q1 = r.ea; return r; }
+        r.b = b;
+        const int eb = __builtin_amdgcn_readfirstlane(seg[b + 1]);
+        r.q1 = q0 + NW < eb ? q0 + NW : eb;
+        return r;
+    };
+    struct Idx { int src; uint32_t d4; };
+    auto load_idx = [&](const Round &r) {  // clamped: never branch around a load; validity is applied where it is used
+        const int q = r.q0 + wave;
+        const int qc = q < r.q1 ? q : (r.q0 < n ? r.q0 : n - 1);
+        const int64_t sb = (sub0 + qc) * SUB_SLOTS;
+        Idx v;
+        v.src = sub_src[sb + r16];
+        v.d4 = *reinterpret_cast<const uint32_t *>(sub_dst + sb + 4 * g);
+        return v;
+    };
+    auto stage = [&](const Round &r, int s, int buf) {
+        float *dst = wbuf + (size_t)buf * 2 * SL * COUT;
+        stage_slice<PIECES, NW>(W + ((size_t)r.a * CIN + (size_t)s * SL) * COUT, dst, wave, lane);
+        if (r.b != r.a) stage_slice<PIECES, NW>(W + ((size_t)r.b * CIN + (size_t)s * SL) * COUT, dst + SL * COUT, wave, lane);
+        asm volatile("" ::: "memory");   // the slices are requested BEFORE the loads that follow (the vmcnt(2) below counts on it)
+    };
+
+    if (n > 0) {
+        Round r0 = plan(0, 0), r1 = plan(r0.q1, r0.b), r2 = plan(r1.q1, r1.b);
+        Idx ic = load_idx(r0), i1 = load_idx(r1), i2 = load_idx(r2);
+        stage(r0, 0, 0);
+        float4 a_c[1][1], a_n[1][1];
+        a_c[0][0] = load_a(X, r0.q0 + wave < r0.q1 ? ic.src : -1, CIN, 4 * g);
+        int phase = 0;
+        while (r0.q0 < n) {
+            const bool valid = r0.q0 + wave < r0.q1;           // wave-uniform
+            const int in_b = (r0.q0 + wave >= r0.ea) ? 1 : 0;  // this wave's sub-chunk belongs to offset b
+            const int rowc = valid ? ic.src : -1, rown = (r1.q0 + wave < r1.q1) ? i1.src : -1;
+            f32x4 acc[1][NT];
+#pragma unroll
+            for (int nn = 0; nn < NT; nn++) acc[0][nn] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int s = 0; s < NS; s++) {
+                // as in the kernel above: the slices staged one phase ago have landed in every wave; only the two index loads of
+                // round r + 2 (the youngest operations of the queue) stay outstanding at a round's first phase
+                if (s == 0 && phase > 0)
+                    asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\t" SEI_BARRIER_INSN ::: "memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" SEI_BARRIER_INSN ::: "memory");
+                const bool same = s + 1 < NS;
+                stage(same ? r0 : r1, same ? s + 1 : 0, (phase + 1) & 1);
+                a_n[0][0] = load_a(X, same ? rowc : rown, CIN, (same ? (s + 1) * SL : 0) + 4 * g);
+                if (valid)
+                    compute_phase<NT, 1, 1, 1, COUT>(wbuf + (size_t)((phase & 1) * 2 + in_b) * SL * COUT, a_c, acc, g, r16);
+                a_c[0][0] = a_n[0][0];
+                phase++;
+            }
+            // tile += partial: offset a's sub-chunks first, then (behind a barrier) offset b's -- the order of the kernel above
+            const int nv = __popcll(__ballot(rowc >= 0) & 0xFFFFull);
+            float *prow[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) prow[i] = acc_tile + ((ic.d4 >> (8 * i)) & 0xFF) * COUT + r16;
+            auto rmw = [&]() {
+                f32x4 tv[NT];
+#pragma unroll
+                for (int nn = 0; nn < NT; nn++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) tv[nn][i] = prow[i][16 * nn];
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    if (4 * g + i < nv) {
+#pragma unroll
+                        for (int nn = 0; nn < NT; nn++) prow[i][16 * nn] = tv[nn][i] + acc[0][nn][i];
+                    }
+            };
+            if (valid && !in_b) rmw();
+            if (r0.q1 > r0.ea) {   // the round holds sub-chunks of b (workgroup-uniform)
+                asm volatile("s_waitcnt lgkmcnt(0)\n\t" SEI_BARRIER_INSN ::: "memory");
+                if (valid && in_b) rmw();
+            }
+            r0 = r1;
+            r1 = r2;
+            r2 = plan(r2.q1, r2.b);
+            ic = i1;
+            i1 = i2;
+            i2 = load_idx(r2);
+        }
+    }
+    __syncthreads();
+    const int64_t row0 = (int64_t)tile * TR;
+    tile_store<TR, COUT, 64 * NW>(acc_tile, Y, row0, n_dst, ldy, ycol0, ep);
+    if (stats) tile_stats<TR, COUT, 64 * NW>(acc_tile, stats, tile, row0, n_dst, ldy, ycol0);
+}
+
 // Stem-type convolutions (tiny nIn, e.g. 1 -> 32 with 125 offsets): all of W sits in LDS, lane = output plane so that
 // every LDS accumulator access is a contiguous row segment.  HBM / LDS bound, no MFMA (64 flop per rule).
 // [r3] no barrier per offset any more: wave w OWNS rows [w TR/4, (w+1) TR/4) of the tile.  A 256-row tile holds ~19 rules
@@ -614,9 +759,22 @@ static ConvPlan plan_tile(int nIn, int nOut, int K, int64_t n_dst) {
                 p.slj = 2; p.blocks = 1;
             }
         }
+#if defined(SEI_EXPERIMENTS) || defined(SEI_TILE_ROUNDS)
+        // two-offset rounds (conv_round_mfma_kernel) for the eight-wave plans: SEI_TILE_ROUNDS=1 in an experiment build
+        if (p.nw == 8 && p.maxs == 1 && K + 1 <= 64) {
+#ifdef SEI_TILE_ROUNDS
+            const bool on = true;
+#else
+            const char *e = getenv("SEI_TILE_ROUNDS");
+            const bool on = e && atoi(e) != 0;
+#endif
+            if (on) { p.g = 2; p.slj = 2; }
+        }
+#endif
 #ifdef SEI_EXPERIMENTS
         int em, ec, es, eb, ew;
         if (env_plan(nOut, &em, &ec, &es, &eb, &ew)) {
+            p.g = 0;
             if (tiles % ec == 0 && em >= 1 && em <= 4 && (ec == 1 || ec == 2)) {
                 p.maxs = em; p.cs = ec; p.blocks = 1; p.nw = 4;
                 p.slj = (nIn % 32 == 0) ? 2 : 1;
@@ -657,6 +815,17 @@ static int launch_mfma(const TiledRules &t, const ConvPlan &p, const float *X, c
     conv_tile_mfma_kernel<NT, CS, SLJ, MAXS, NW><<<((t.n_tiles * p.blocks + 7) / 8) * 8, 64 * NW, p.lds_bytes, st>>>(
         X, W, bias, Y, t.tile_sub_start, t.tile_seg, t.sub_src, t.sub_dst, t.n_dst, t.K, nIn, t.n_tiles, init,
         NT * CS * 16 * p.blocks, p.blocks, stats, ep);
+    SEI_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int NT>
+static int launch_round(const TiledRules &t, const ConvPlan &p, const float *X, const float *W, const float *bias, float *Y,
+                        int nIn, const float *init, double *stats, hipStream_t st, const ConvEpilogue &ep) {
+    SEI_TRY(ensure_max_lds((const void *)conv_round_mfma_kernel<NT, 8>, 160 * 1024));
+    conv_round_mfma_kernel<NT, 8><<<((t.n_tiles * p.blocks + 7) / 8) * 8, 512, p.lds_bytes, st>>>(
+        X, W, bias, Y, t.tile_sub_start, t.tile_seg, t.sub_src, t.sub_dst, t.n_dst, t.K, nIn, t.n_tiles, init,
+        NT * 16 * p.blocks, p.blocks, stats, ep);
     SEI_LAUNCH_CHECK();
     return 0;
 }
@@ -738,6 +907,13 @@ int conv_forward(const TiledRules &t, const float *X, const float *W, const floa
     if (p.kind == 2) return conv_forward_wave(t, p, X, W, bias, Y, nIn, nOut, init, stats, st, epv);
     if (p.kind == 3) return conv_forward_band(t, p, X, W, bias, Y, nIn, nOut, init, stats, st);
     if (p.kind == 4) return conv_forward_cols(t, p, X, W, bias, Y, nIn, nOut, init, stats, st, epv);
+    if (p.kind == 1 && p.g == 2) {
+        if (nIn % 16) SEI_FAIL("conv_forward: the round kernel needs nIn % 16 == 0");
+#define ROUND_CASE(NT_) if (p.nt == NT_) return launch_round<NT_>(t, p, X, W, bias, Y, nIn, init, stats, st, epv);
+        ROUND_CASE(3) ROUND_CASE(4) ROUND_CASE(5) ROUND_CASE(6)
+#undef ROUND_CASE
+        SEI_FAIL("conv_forward: no round-kernel instantiation for this plan");
+    }
     if (p.kind == 1) {
         // eight-wave workgroups: 96 columns in one block, 128 / 160 (and 96 behind a 16-plane input) in two column blocks
         FWD_CASE8(3) FWD_CASE8(4) FWD_CASE8(5) FWD_CASE8S2(6)

@@ -40,7 +40,8 @@ def main():
     for rnd in range(a.rounds):        # plans interleaved over several rounds: clocks drift during a run
         for plan in a.plans:
             os.environ["SEI_CONV_KERNEL"] = "cols" if plan == "cols" else "tile"   # "cols": the column-owner kernel (conv_cols.hip)
-            if plan in ("default", "cols"):
+            os.environ["SEI_TILE_ROUNDS"] = "1" if plan == "rounds" else "0"     # "rounds": conv_round_mfma_kernel (two-offset rounds)
+            if plan in ("default", "cols", "rounds"):
                 os.environ.pop("SEI_FWD_PLAN", None)
             else:
                 os.environ["SEI_FWD_PLAN"] = plan
