@@ -19,6 +19,7 @@
 
 #include <stdlib.h>
 #include <string.h>
+#include <utility>
 
 #ifdef SEI_ABL_NOBAR  // diagnostic: the per-phase workgroup barrier removed (results are wrong, timing only)
 #define SEI_BARRIER_INSN "s_nop 0"
@@ -403,14 +404,28 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? occ8_for(NT, CS, SLJ, MAXS) : o
 // MFMA chain over the input planes added to the tile once, and inside a round the sub-chunks of a are added before those of
 // b (one extra barrier per round that holds both); rows of one offset are distinct, so results are bit-identical to the
 // kernel above.
+template <class F, int... S>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, S...>) {
+    (f(std::integral_constant<int, S>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {   // f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>)
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
 struct Round {
     int q0, q1;   // tile-relative sub-chunks [q0, q1)
     int a, b;     // their offsets: a for q < ea, b from ea on (b == a: a alone)
     int ea;
 };
 
-template <int NT, int NW>
-__global__ __launch_bounds__(64 * NW, occ8_for(NT, 1, 2, 1)) void conv_round_mfma_kernel(
+// NJ > 0: nIn == 16 NJ and the A fragments of a wave's NEXT sub-chunk (all NJ slices) are gathered in one burst during the
+// first phase of the current round, behind that phase's slice request: memory operations retire in order, so a gather
+// requested per phase (NJ == 0, as in the kernel above) has ONE phase to land before the next barrier's vmcnt wait needs the
+// slice behind it -- with 16-plane slices a phase is shorter than a gather's latency, every phase waited for one.  The burst
+// has two phases, and the four phases after them wait for L2-resident weight slices only.
+template <int NT, int NW, int NJ>
+__global__ __launch_bounds__(64 * NW, (NJ > 0 ? 4 : occ8_for(NT, 1, 2, 1))) void conv_round_mfma_kernel(
     const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ Y,
     const int32_t *__restrict__ tile_sub_start, const int32_t *__restrict__ tile_seg,
     const int32_t *__restrict__ sub_src, const uint8_t *__restrict__ sub_dst, int64_t n_dst, int K, int CIN, int n_tiles,
@@ -429,6 +444,7 @@ __global__ __launch_bounds__(64 * NW, occ8_for(NT, 1, 2, 1)) void conv_round_mfm
     float *wbuf = lds + (size_t)TR * COUT;   // [buffer][offset half][SL][COUT]
     int *seg = reinterpret_cast<int *>(wbuf + 4 * SL * COUT);
 
+    TRACE_DECL;
     for (int i = threadIdx.x; i <= K; i += 64 * NW) seg[i] = tile_seg[(size_t)tile * (K + 1) + i];
     tile_init<TR, COUT, 64 * NW>(acc_tile, bias, init, (int64_t)tile * TR, n_dst, ldy, ycol0);
     __syncthreads();
@@ -475,8 +491,10 @@ __global__ __launch_bounds__(64 * NW, occ8_for(NT, 1, 2, 1)) void conv_round_mfm
         Round r0 = plan(0, 0), r1 = plan(r0.q1, r0.b), r2 = plan(r1.q1, r1.b);
         Idx ic = load_idx(r0), i1 = load_idx(r1), i2 = load_idx(r2);
         stage(r0, 0, 0);
-        float4 a_c[1][1], a_n[1][1];
-        a_c[0][0] = load_a(X, r0.q0 + wave < r0.q1 ? ic.src : -1, CIN, 4 * g);
+        constexpr int NA = NJ > 0 ? NJ : 1;
+        float4 a_c[NA][1][1], a_n[1][1][1];
+#pragma unroll
+        for (int j = 0; j < NA; j++) a_c[j][0][0] = load_a(X, r0.q0 + wave < r0.q1 ? ic.src : -1, CIN, 16 * j + 4 * g);
         int phase = 0;
         while (r0.q0 < n) {
             const bool valid = r0.q0 + wave < r0.q1;           // wave-uniform
@@ -485,6 +503,51 @@ __global__ __launch_bounds__(64 * NW, occ8_for(NT, 1, 2, 1)) void conv_round_mfm
             f32x4 acc[1][NT];
 #pragma unroll
             for (int nn = 0; nn < NT; nn++) acc[0][nn] = f32x4{0.f, 0.f, 0.f, 0.f};
+            Round r3 = r2;
+            Idx i3 = i2;
+            if constexpr (NJ > 0) {
+                static_assert(NJ == 0 || NJ >= 4, "the schedule below uses phases 0..3");
+                // ONE set of A fragments: a_c[s] holds slice s of the wave's current sub-chunk until phase s has used it and is
+                // refilled in the NEXT phase -- with slice s of the next round's sub-chunk (slice NJ-1: of the current one, it is
+                // used last) -- so a gather has NJ-1 phases to be used and, memory operations retiring in order, two phases to land
+                // (the barrier of phase p+2 waits for the slice requested in phase p+1, which sits behind it in the queue).
+                // Queue of one phase: [slice a][slice b][gather]([index loads x 2] in phase 2).
+                static_for<NJ>([&](auto sc) {
+                    constexpr int s = decltype(sc)::value;
+                    if (phase == 0)
+                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" SEI_BARRIER_INSN ::: "memory");
+                    else if (s == 3)
+                        asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\t" SEI_BARRIER_INSN ::: "memory");
+                    else
+                        asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\t" SEI_BARRIER_INSN ::: "memory");
+                    TRACE(0);
+                    {
+                        // the gather of two phases ago (into a_c[s-3]) is in: tell hipcc here, so that it plants no wait of its own
+                        constexpr int jg = (s + NJ - 3) % NJ;
+                        asm volatile("" : "+v"(a_c[jg][0][0].x), "+v"(a_c[jg][0][0].y), "+v"(a_c[jg][0][0].z), "+v"(a_c[jg][0][0].w));
+                    }
+                    const bool same = s + 1 < NJ;
+                    stage(same ? r0 : r1, same ? s + 1 : 0, (phase + 1) & 1);
+                    {
+                        constexpr int jr = (s + NJ - 1) % NJ;   // the fragment the previous phase used
+                        a_c[jr][0][0] = load_a(X, s == 0 ? rowc : rown, CIN, 16 * jr + 4 * g);
+                        asm volatile("" ::: "memory");
+                    }
+                    if (s == 2) {
+                        // the index words of round r + 3 are requested mid-round into registers of their own and move over at
+                        // the end of the round, long after they have arrived (requested at the end of the round, hipcc loaded
+                        // them into spare registers and waited vmcnt(0) for the copy right there)
+                        r3 = plan(r2.q1, r2.b);
+                        i3 = load_idx(r3);
+                        asm volatile("" ::: "memory");
+                    }
+                    TRACE(1);
+                    if (valid)
+                        compute_phase<NT, 1, 1, 1, COUT>(wbuf + (size_t)((phase & 1) * 2 + in_b) * SL * COUT, a_c[s], acc, g, r16);
+                    TRACE(2 | ((valid ? 1 : 0) << 2));
+                    phase++;
+                });
+            } else
             for (int s = 0; s < NS; s++) {
                 // as in the kernel above: the slices staged one phase ago have landed in every wave; only the two index loads of
                 // round r + 2 (the youngest operations of the queue) stay outstanding at a round's first phase
@@ -492,12 +555,15 @@ __global__ __launch_bounds__(64 * NW, occ8_for(NT, 1, 2, 1)) void conv_round_mfm
                     asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\t" SEI_BARRIER_INSN ::: "memory");
                 else
                     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" SEI_BARRIER_INSN ::: "memory");
+                TRACE(0);
                 const bool same = s + 1 < NS;
                 stage(same ? r0 : r1, same ? s + 1 : 0, (phase + 1) & 1);
-                a_n[0][0] = load_a(X, same ? rowc : rown, CIN, (same ? (s + 1) * SL : 0) + 4 * g);
+                a_n[0][0][0] = load_a(X, same ? rowc : rown, CIN, (same ? (s + 1) * SL : 0) + 4 * g);
+                TRACE(1);
                 if (valid)
-                    compute_phase<NT, 1, 1, 1, COUT>(wbuf + (size_t)((phase & 1) * 2 + in_b) * SL * COUT, a_c, acc, g, r16);
-                a_c[0][0] = a_n[0][0];
+                    compute_phase<NT, 1, 1, 1, COUT>(wbuf + (size_t)((phase & 1) * 2 + in_b) * SL * COUT, a_c[0], acc, g, r16);
+                TRACE(2 | ((valid ? 1 : 0) << 2));
+                a_c[0][0][0] = a_n[0][0][0];
                 phase++;
             }
             // tile += partial: offset a's sub-chunks first, then (behind a barrier) offset b's -- the order of the kernel above
@@ -523,18 +589,25 @@ __global__ __launch_bounds__(64 * NW, occ8_for(NT, 1, 2, 1)) void conv_round_mfm
                 asm volatile("s_waitcnt lgkmcnt(0)\n\t" SEI_BARRIER_INSN ::: "memory");
                 if (valid && in_b) rmw();
             }
+            TRACE(3);
             r0 = r1;
             r1 = r2;
-            r2 = plan(r2.q1, r2.b);
             ic = i1;
             i1 = i2;
-            i2 = load_idx(r2);
+            if constexpr (NJ > 0) {
+                r2 = r3;
+                i2 = i3;
+            } else {
+                r2 = plan(r2.q1, r2.b);
+                i2 = load_idx(r2);
+            }
         }
     }
     __syncthreads();
     const int64_t row0 = (int64_t)tile * TR;
     tile_store<TR, COUT, 64 * NW>(acc_tile, Y, row0, n_dst, ldy, ycol0, ep);
     if (stats) tile_stats<TR, COUT, 64 * NW>(acc_tile, stats, tile, row0, n_dst, ldy, ycol0);
+    TRACE_END;
 }
 
 // Stem-type convolutions (tiny nIn, e.g. 1 -> 32 with 125 offsets): all of W sits in LDS, lane = output plane so that
@@ -761,7 +834,7 @@ static ConvPlan plan_tile(int nIn, int nOut, int K, int64_t n_dst) {
         }
 #if defined(SEI_EXPERIMENTS) || defined(SEI_TILE_ROUNDS)
         // two-offset rounds (conv_round_mfma_kernel) for the eight-wave plans: SEI_TILE_ROUNDS=1 in an experiment build
-        if (p.nw == 8 && p.maxs == 1 && K + 1 <= 64) {
+        if (p.nw == 8 && p.maxs == 1 && K + 1 <= 64 && nIn >= 64) {   // the round schedule uses phases 0..3: nIn / 16 >= 4
 #ifdef SEI_TILE_ROUNDS
             const bool on = true;
 #else
@@ -822,8 +895,21 @@ static int launch_mfma(const TiledRules &t, const ConvPlan &p, const float *X, c
 template <int NT>
 static int launch_round(const TiledRules &t, const ConvPlan &p, const float *X, const float *W, const float *bias, float *Y,
                         int nIn, const float *init, double *stats, hipStream_t st, const ConvEpilogue &ep) {
-    SEI_TRY(ensure_max_lds((const void *)conv_round_mfma_kernel<NT, 8>, 160 * 1024));
-    conv_round_mfma_kernel<NT, 8><<<((t.n_tiles * p.blocks + 7) / 8) * 8, 512, p.lds_bytes, st>>>(
+#ifdef SEI_ROUND_NOBURST
+    constexpr bool burst_ok = false;
+#else
+    constexpr bool burst_ok = NT == 6;   // 96 columns in one block: two workgroups per CU, 128 registers each
+#endif
+    if (burst_ok && nIn == 96) {
+        SEI_TRY(ensure_max_lds((const void *)conv_round_mfma_kernel<NT, 8, 6>, 160 * 1024));
+        conv_round_mfma_kernel<NT, 8, 6><<<((t.n_tiles * p.blocks + 7) / 8) * 8, 512, p.lds_bytes, st>>>(
+            X, W, bias, Y, t.tile_sub_start, t.tile_seg, t.sub_src, t.sub_dst, t.n_dst, t.K, nIn, t.n_tiles, init,
+            NT * 16 * p.blocks, p.blocks, stats, ep);
+        SEI_LAUNCH_CHECK();
+        return 0;
+    }
+    SEI_TRY(ensure_max_lds((const void *)conv_round_mfma_kernel<NT, 8, 0>, 160 * 1024));
+    conv_round_mfma_kernel<NT, 8, 0><<<((t.n_tiles * p.blocks + 7) / 8) * 8, 512, p.lds_bytes, st>>>(
         X, W, bias, Y, t.tile_sub_start, t.tile_seg, t.sub_src, t.sub_dst, t.n_dst, t.K, nIn, t.n_tiles, init,
         NT * 16 * p.blocks, p.blocks, stats, ep);
     SEI_LAUNCH_CHECK();
@@ -908,7 +994,7 @@ int conv_forward(const TiledRules &t, const float *X, const float *W, const floa
     if (p.kind == 3) return conv_forward_band(t, p, X, W, bias, Y, nIn, nOut, init, stats, st);
     if (p.kind == 4) return conv_forward_cols(t, p, X, W, bias, Y, nIn, nOut, init, stats, st, epv);
     if (p.kind == 1 && p.g == 2) {
-        if (nIn % 16) SEI_FAIL("conv_forward: the round kernel needs nIn % 16 == 0");
+        if (nIn % 16 || nIn < 64) SEI_FAIL("conv_forward: the round kernel needs nIn % 16 == 0 and nIn >= 64");
 #define ROUND_CASE(NT_) if (p.nt == NT_) return launch_round<NT_>(t, p, X, W, bias, Y, nIn, init, stats, st, epv);
         ROUND_CASE(3) ROUND_CASE(4) ROUND_CASE(5) ROUND_CASE(6)
 #undef ROUND_CASE
