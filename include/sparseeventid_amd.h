@@ -146,9 +146,11 @@ int sei_set_backward_streams(int32_t mode);
 /* `stream` waits for everything sei_conv_backward queued on its side stream so far (no-op if nothing was) */
 int sei_backward_join(sei_stream_t stream);
 /* Test / sweep hook: pins the forward / dX kernel family for every later convolution of the process
- * (0 = the plan picks (default), 1 = workgroup-tile kernel, 2 = wave-private kernel, 3 = row-band kernel: experiment
- * builds only, the shipped library returns an error for it).  The families produce bit-identical results (same per-row
- * summation order); tests/test_gpu_kernels_agree.py asserts it. */
+ * (0 = the plan picks (default), 1 = workgroup-tile kernel with one filter offset per phase everywhere, 2 = wave-private
+ * kernel, 5 = the tile kernel's two-offset-round form wherever it is instantiated (the default uses it for the 96 / 128 /
+ * 160-column layers of large levels); 3 = row-band kernel and 4 = column-owner kernel: experiment builds only, the shipped
+ * library returns an error for them).  The families produce bit-identical results (same per-row summation order);
+ * tests/test_gpu_kernels_agree.py asserts it. */
 int sei_debug_force_conv_kernel(int32_t kind);
 /* Same for the dW kernel: 0 = the library's choice, 1 = register-operand kernel, 2 = LDS-operand (ring) kernel -- an
  * experiment that measured slower and is compiled only with EXTRA=-DSEI_EXPERIMENTS (the shipped library returns an

@@ -298,6 +298,7 @@ int forced_conv_kernel() {
         if (!strcmp(e, "wave")) return CONV_KERNEL_WAVE;
         if (!strcmp(e, "band")) return CONV_KERNEL_BAND;
         if (!strcmp(e, "cols")) return CONV_KERNEL_COLS;
+        if (!strcmp(e, "rounds")) return CONV_KERNEL_ROUNDS;
     }
 #endif
     return g_force_kernel.load(std::memory_order_relaxed);
@@ -926,9 +927,10 @@ int sei_debug_force_dw_kernel(int32_t kind) {
 }
 
 int sei_debug_force_conv_kernel(int32_t kind) {
-    if (kind < CONV_KERNEL_AUTO || kind > CONV_KERNEL_COLS) SEI_FAIL("sei_debug_force_conv_kernel: kind must be 0..4");
+    if (kind < CONV_KERNEL_AUTO || kind > CONV_KERNEL_ROUNDS) SEI_FAIL("sei_debug_force_conv_kernel: kind must be 0..5");
 #ifndef SEI_EXPERIMENTS
     if (kind == CONV_KERNEL_BAND) SEI_FAIL("sei_debug_force_conv_kernel: the row-band kernels exist only in experiment builds (make EXTRA=-DSEI_EXPERIMENTS)");
+    if (kind == CONV_KERNEL_COLS) SEI_FAIL("sei_debug_force_conv_kernel: the column-owner kernel exists only in experiment builds (make EXTRA=-DSEI_EXPERIMENTS)");
 #endif
     g_force_kernel.store(kind);
     return 0;

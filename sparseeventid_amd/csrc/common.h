@@ -294,14 +294,16 @@ struct ConvPlan {
     int tile_rows = 0;   // rulebook variant (dst rows per tile)
     int col_group = 0;   // kind 1: width of the column groups whose columns are stored permuted (0 = natural layout)
     int blocks = 1;      // column blocks (kind 1: weights stored as [block][K][nIn][nOut/blocks])
-    int nt = 0, cs = 0, slj = 0, maxs = 0, g = 0;
+    int nt = 0, cs = 0, slj = 0, maxs = 0, g = 0;   // kind 1, g == 2: two-offset rounds (conv_round_mfma_kernel), g == 3: with refilled A fragments
     int nw = 4;          // kind 1: waves per workgroup (4 or 8)
     size_t lds_bytes = 0;
 };
 ConvPlan plan_conv(int nIn, int nOut, int K, int64_t n_dst);
 // sei_debug_force_conv_kernel(): pins the forward / dX kernel family for every later call of the process
 // (bit-identity tests between the kernels, sweeps); AUTO = the plan picks
-enum { CONV_KERNEL_AUTO = 0, CONV_KERNEL_TILE = 1, CONV_KERNEL_WAVE = 2, CONV_KERNEL_BAND = 3, CONV_KERNEL_COLS = 4 };
+// TILE: the workgroup-tile kernel with one offset per phase everywhere; ROUNDS: its two-offset-round form wherever it is instantiated
+// (AUTO uses that form for the eight-wave plans); BAND / COLS: experiment builds only
+enum { CONV_KERNEL_AUTO = 0, CONV_KERNEL_TILE = 1, CONV_KERNEL_WAVE = 2, CONV_KERNEL_BAND = 3, CONV_KERNEL_COLS = 4, CONV_KERNEL_ROUNDS = 5 };
 int forced_conv_kernel();
 // sei_debug_force_dw_kernel(): dW kernel family (AUTO = the library's choice)
 enum { DW_KERNEL_AUTO = 0, DW_KERNEL_REG = 1, DW_KERNEL_RING = 2 };

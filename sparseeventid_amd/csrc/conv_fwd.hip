@@ -496,13 +496,40 @@ __global__ __launch_bounds__(64 * NW, (NJ > 0 ? 4 : occ8_for(NT, 1, 2, 1))) void
 #pragma unroll
         for (int j = 0; j < NA; j++) a_c[j][0][0] = load_a(X, r0.q0 + wave < r0.q1 ? ic.src : -1, CIN, 16 * j + 4 * g);
         int phase = 0;
+        // tile rows += partial sums of the sub-chunk a wave held (d4: its packed dst rows, nv: rule slots in it)
+        f32x4 acc[1][NT];
+        auto rmw = [&](uint32_t d4, int nv) {
+            float *prow[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) prow[i] = acc_tile + ((d4 >> (8 * i)) & 0xFF) * COUT + r16;
+            f32x4 tv[NT];
+#pragma unroll
+            for (int nn = 0; nn < NT; nn++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) tv[nn][i] = prow[i][16 * nn];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                if (4 * g + i < nv) {
+#pragma unroll
+                    for (int nn = 0; nn < NT; nn++) prow[i][16 * nn] = tv[nn][i] + acc[0][nn][i];
+                }
+        };
+        // The sub-chunks of offset b are added after those of a.  Instead of a barrier of its own between the two groups, a wave
+        // that held a b sub-chunk keeps its sums and adds them BEHIND THE FIRST BARRIER OF THE NEXT ROUND (which is there anyway),
+        // before it clears its accumulators; the a sub-chunks of that round are added six barriers later.
+        bool pend_b = false;
+        uint32_t pend_d4 = 0;
+        int pend_nv = 0;
+        auto round_begin = [&]() {   // first thing behind a round's first barrier
+            if (pend_b) rmw(pend_d4, pend_nv);
+            pend_b = false;
+#pragma unroll
+            for (int nn = 0; nn < NT; nn++) acc[0][nn] = f32x4{0.f, 0.f, 0.f, 0.f};
+        };
         while (r0.q0 < n) {
             const bool valid = r0.q0 + wave < r0.q1;           // wave-uniform
             const int in_b = (r0.q0 + wave >= r0.ea) ? 1 : 0;  // this wave's sub-chunk belongs to offset b
             const int rowc = valid ? ic.src : -1, rown = (r1.q0 + wave < r1.q1) ? i1.src : -1;
-            f32x4 acc[1][NT];
-#pragma unroll
-            for (int nn = 0; nn < NT; nn++) acc[0][nn] = f32x4{0.f, 0.f, 0.f, 0.f};
             Round r3 = r2;
             Idx i3 = i2;
             if constexpr (NJ > 0) {
@@ -521,6 +548,7 @@ __global__ __launch_bounds__(64 * NW, (NJ > 0 ? 4 : occ8_for(NT, 1, 2, 1))) void
                     else
                         asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\t" SEI_BARRIER_INSN ::: "memory");
                     TRACE(0);
+                    if (s == 0) round_begin();
                     {
                         // the gather of two phases ago (into a_c[s-3]) is in: tell hipcc here, so that it plants no wait of its own
                         constexpr int jg = (s + NJ - 3) % NJ;
@@ -556,6 +584,7 @@ __global__ __launch_bounds__(64 * NW, (NJ > 0 ? 4 : occ8_for(NT, 1, 2, 1))) void
                 else
                     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" SEI_BARRIER_INSN ::: "memory");
                 TRACE(0);
+                if (s == 0) round_begin();
                 const bool same = s + 1 < NS;
                 stage(same ? r0 : r1, same ? s + 1 : 0, (phase + 1) & 1);
                 a_n[0][0][0] = load_a(X, same ? rowc : rown, CIN, (same ? (s + 1) * SL : 0) + 4 * g);
@@ -566,28 +595,12 @@ __global__ __launch_bounds__(64 * NW, (NJ > 0 ? 4 : occ8_for(NT, 1, 2, 1))) void
                 a_c[0][0][0] = a_n[0][0][0];
                 phase++;
             }
-            // tile += partial: offset a's sub-chunks first, then (behind a barrier) offset b's -- the order of the kernel above
             const int nv = __popcll(__ballot(rowc >= 0) & 0xFFFFull);
-            float *prow[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++) prow[i] = acc_tile + ((ic.d4 >> (8 * i)) & 0xFF) * COUT + r16;
-            auto rmw = [&]() {
-                f32x4 tv[NT];
-#pragma unroll
-                for (int nn = 0; nn < NT; nn++)
-#pragma unroll
-                    for (int i = 0; i < 4; i++) tv[nn][i] = prow[i][16 * nn];
-#pragma unroll
-                for (int i = 0; i < 4; i++)
-                    if (4 * g + i < nv) {
-#pragma unroll
-                        for (int nn = 0; nn < NT; nn++) prow[i][16 * nn] = tv[nn][i] + acc[0][nn][i];
-                    }
-            };
-            if (valid && !in_b) rmw();
-            if (r0.q1 > r0.ea) {   // the round holds sub-chunks of b (workgroup-uniform)
-                asm volatile("s_waitcnt lgkmcnt(0)\n\t" SEI_BARRIER_INSN ::: "memory");
-                if (valid && in_b) rmw();
+            if (valid && !in_b) rmw(ic.d4, nv);
+            if (valid && in_b) {
+                pend_b = true;
+                pend_d4 = ic.d4;
+                pend_nv = nv;
             }
             TRACE(3);
             r0 = r1;
@@ -602,6 +615,8 @@ __global__ __launch_bounds__(64 * NW, (NJ > 0 ? 4 : occ8_for(NT, 1, 2, 1))) void
                 i2 = load_idx(r2);
             }
         }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" SEI_BARRIER_INSN ::: "memory");
+        if (pend_b) rmw(pend_d4, pend_nv);
     }
     __syncthreads();
     const int64_t row0 = (int64_t)tile * TR;
@@ -817,7 +832,8 @@ static ConvPlan plan_tile(int nIn, int nOut, int K, int64_t n_dst) {
             }
         }
         p.slj = (nIn % 32 == 0) ? 2 : 1;
-        if (nOut == 96 || ((nOut == 128 || nOut == 160) && n_dst >= 100000)) {
+        const int kind_forced = forced_conv_kernel();
+        if (nOut == 96 || ((nOut == 128 || nOut == 160) && (n_dst >= 100000 || kind_forced == CONV_KERNEL_ROUNDS))) {
             // 96 / 128 / 160 columns: eight-wave workgroups -- one sub-chunk per wave and offset on 128-row tiles, two
             // column blocks, 16-plane weight slices: 30-50 KB of LDS and 60-90 VGPRs (no spills), three or four
             // workgroups (24-32 waves) per CU.  A phase is one latency chain (barrier -> B from LDS -> MFMA -> LDS
@@ -832,18 +848,18 @@ static ConvPlan plan_tile(int nIn, int nOut, int K, int64_t n_dst) {
                 p.slj = 2; p.blocks = 1;
             }
         }
-#if defined(SEI_EXPERIMENTS) || defined(SEI_TILE_ROUNDS)
-        // two-offset rounds (conv_round_mfma_kernel) for the eight-wave plans: SEI_TILE_ROUNDS=1 in an experiment build
-        if (p.nw == 8 && p.maxs == 1 && K + 1 <= 64 && nIn >= 64) {   // the round schedule uses phases 0..3: nIn / 16 >= 4
-#ifdef SEI_TILE_ROUNDS
-            const bool on = true;
-#else
-            const char *e = getenv("SEI_TILE_ROUNDS");
-            const bool on = e && atoi(e) != 0;
+        // Two-offset rounds (conv_round_mfma_kernel) for the eight-wave plans: 84.7 / 87.1 / 86.2 against 75.3 / 81.2 / 80.7
+        // TFLOP/s at 96 / 128 / 160 planes of the 64-event batch (profiles/r04_conv_round_ab.log), bit-identical.  The A
+        // fragments live in one refilled register set where two workgroups per CU are the plan anyway (96 columns in one
+        // block: 110 registers) and at 160 planes (2 x 80 columns: 122 registers, two workgroups instead of three, +7 %);
+        // the 2 x 64-column blocks of 128 planes keep per-phase gathers and three workgroups (the two forms measured equal).
+        if (p.nw == 8 && p.maxs == 1 && nIn >= 64 && kind_forced != CONV_KERNEL_TILE) {   // the schedule uses phases 0..3
+            bool on = true;
+#ifdef SEI_EXPERIMENTS
+            if (const char *e = getenv("SEI_TILE_ROUNDS")) on = atoi(e) != 0;
 #endif
             if (on) { p.g = 2; p.slj = 2; }
         }
-#endif
 #ifdef SEI_EXPERIMENTS
         int em, ec, es, eb, ew;
         if (env_plan(nOut, &em, &ec, &es, &eb, &ew)) {
@@ -895,19 +911,25 @@ static int launch_mfma(const TiledRules &t, const ConvPlan &p, const float *X, c
 template <int NT>
 static int launch_round(const TiledRules &t, const ConvPlan &p, const float *X, const float *W, const float *bias, float *Y,
                         int nIn, const float *init, double *stats, hipStream_t st, const ConvEpilogue &ep) {
-#ifdef SEI_ROUND_NOBURST
-    constexpr bool burst_ok = false;
-#else
-    constexpr bool burst_ok = NT == 6;   // 96 columns in one block: two workgroups per CU, 128 registers each
+    // one register set of A fragments refilled a phase after use (NJ = nIn / 16 > 0) where 128 registers hold it; the narrower
+    // column blocks keep the per-phase gathers and three workgroups per CU
+    bool jit = NT == 6 || NT == 5;
+#ifdef SEI_EXPERIMENTS
+    if (const char *e = getenv("SEI_ROUND_JIT")) jit = atoi(e) != 0;
 #endif
-    if (burst_ok && nIn == 96) {
-        SEI_TRY(ensure_max_lds((const void *)conv_round_mfma_kernel<NT, 8, 6>, 160 * 1024));
-        conv_round_mfma_kernel<NT, 8, 6><<<((t.n_tiles * p.blocks + 7) / 8) * 8, 512, p.lds_bytes, st>>>(
-            X, W, bias, Y, t.tile_sub_start, t.tile_seg, t.sub_src, t.sub_dst, t.n_dst, t.K, nIn, t.n_tiles, init,
-            NT * 16 * p.blocks, p.blocks, stats, ep);
-        SEI_LAUNCH_CHECK();
-        return 0;
+#define ROUND_JIT(NJ_)                                                                                              \
+    if (jit && nIn == 16 * NJ_) {                                                                                   \
+        SEI_TRY(ensure_max_lds((const void *)conv_round_mfma_kernel<NT, 8, NJ_>, 160 * 1024));                      \
+        conv_round_mfma_kernel<NT, 8, NJ_><<<((t.n_tiles * p.blocks + 7) / 8) * 8, 512, p.lds_bytes, st>>>(         \
+            X, W, bias, Y, t.tile_sub_start, t.tile_seg, t.sub_src, t.sub_dst, t.n_dst, t.K, nIn, t.n_tiles, init,  \
+            NT * 16 * p.blocks, p.blocks, stats, ep);                                                               \
+        SEI_LAUNCH_CHECK();                                                                                         \
+        return 0;                                                                                                   \
     }
+    if constexpr (NT == 6) { ROUND_JIT(4) ROUND_JIT(6) ROUND_JIT(8) }
+    if constexpr (NT == 4) { ROUND_JIT(6) ROUND_JIT(8) ROUND_JIT(10) }
+    if constexpr (NT == 5) { ROUND_JIT(8) ROUND_JIT(10) ROUND_JIT(12) }
+#undef ROUND_JIT
     SEI_TRY(ensure_max_lds((const void *)conv_round_mfma_kernel<NT, 8, 0>, 160 * 1024));
     conv_round_mfma_kernel<NT, 8, 0><<<((t.n_tiles * p.blocks + 7) / 8) * 8, 512, p.lds_bytes, st>>>(
         X, W, bias, Y, t.tile_sub_start, t.tile_seg, t.sub_src, t.sub_dst, t.n_dst, t.K, nIn, t.n_tiles, init,

@@ -22,16 +22,18 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
-CONV_KERNELS = {"default": 0, "tile": 1, "wave": 2, "band": 3}
+CONV_KERNELS = {"default": 0, "tile": 1, "wave": 2, "band": 3, "cols": 4, "rounds": 5}
 
 
 def conv_families():
-    """the forward / dX kernel families of the loaded library: the row-band family exists only in experiment builds
-    (make -C sparseeventid_amd/csrc -B EXTRA=-DSEI_EXPERIMENTS); the shipped library refuses to pin it"""
+    """the forward / dX kernel families of the loaded library: tile (one offset per phase), wave-private, the tile kernel's
+    two-offset rounds; the row-band and column-owner families exist only in experiment builds
+    (make -C sparseeventid_amd/csrc -B EXTRA=-DSEI_EXPERIMENTS): the shipped library refuses to pin them"""
     from sparseeventid_amd._lib import lib
-    fams = ["tile", "wave"]
-    if lib().sei_debug_force_conv_kernel(CONV_KERNELS["band"]) == 0:
-        fams.append("band")
+    fams = ["tile", "wave", "rounds"]
+    for extra in ("band", "cols"):
+        if lib().sei_debug_force_conv_kernel(CONV_KERNELS[extra]) == 0:
+            fams.append(extra)
     lib().sei_debug_force_conv_kernel(0)
     return tuple(fams)
 
@@ -45,8 +47,8 @@ def force_conv_kernel():
 
     def force(kind):
         rc = lib().sei_debug_force_conv_kernel(CONV_KERNELS[kind])
-        if rc != 0 and kind == "band":
-            pytest.skip("library built without -DSEI_EXPERIMENTS: no row-band kernels")
+        if rc != 0 and kind in ("band", "cols"):
+            pytest.skip("library built without -DSEI_EXPERIMENTS: no row-band / column-owner kernels")
         assert rc == 0
     yield force
     lib().sei_debug_force_conv_kernel(0)

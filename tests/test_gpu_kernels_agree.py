@@ -1,5 +1,6 @@
-"""GPU: the forward / dX kernel families -- workgroup-tile (conv_fwd.hip), wave-private (conv_wave.hip) and, in experiment
-builds only, row-band (conv_band.hip: row-band ownership + LDS weight ring filled by a loader wave) -- keep the SAME per-row summation order
+"""GPU: the forward / dX kernel families -- workgroup-tile with one offset per phase and with two-offset rounds (conv_fwd.hip),
+wave-private (conv_wave.hip) and, in experiment builds only, row-band (conv_band.hip: row-band ownership + LDS weight ring
+filled by a loader wave) and column-owner (conv_cols.hip) -- keep the SAME per-row summation order
 (offsets ascending; inside an offset one MFMA chain over the input planes, then tile += partial), so their results are
 bit-identical: forward, dX, dX with the skip gradient folded in, and the BatchNorm statistics of the epilogue.  The
 row-band kernel's bounded poll loops must never run out (sei_debug_band_timeouts)."""
@@ -94,19 +95,19 @@ def test_fused_residual_block_bit_identical_across_families(force_conv_kernel):
     assert _timeouts() == 0
 
 
-def test_band_kernel_strided_and_transposed_rules(force_conv_kernel):
-    """scn.Convolution 2^3 / stride 2 (forward rules) and its dX (transposed rulebook) through the row-band kernel."""
+@pytest.mark.parametrize("ci,co", [(96, 128), (64, 96), (128, 160)])
+def test_strided_and_transposed_rules_across_families(ci, co, force_conv_kernel):
+    """scn.Convolution 2^3 / stride 2 (forward rules, 8 offsets) and its dX (transposed rulebook) through every family: the
+    two-offset rounds of the tile kernel see rounds cut by the end of the offset list, the row-band kernel its ring."""
     import sparseeventid_amd.scn as scn
     _timeouts(reset=True)
     sp, B = [31, 29, 33], 2
     t = _cloud(91, B, sp, 3000)
     n = t.features.shape[0]
-    x = torch.randn(n, 96, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
-    conv = scn.Convolution(3, 96, 128, 2, 2, False).cuda()
+    x = torch.randn(n, ci, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    conv = scn.Convolution(3, ci, co, 2, 2, False).cuda()
     res = {}
     FAMILIES = conv_families()
-    if "band" not in FAMILIES:
-        pytest.skip("library built without -DSEI_EXPERIMENTS: no row-band kernels")
     for fam in FAMILIES:
         force_conv_kernel(fam)
         xx = x.clone().requires_grad_(True)
