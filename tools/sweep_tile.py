@@ -39,12 +39,12 @@ def main():
     R = rb.n_rules
     for rnd in range(a.rounds):        # plans interleaved over several rounds: clocks drift during a run
         for plan in a.plans:
-            os.environ["SEI_CONV_KERNEL"] = "cols" if plan == "cols" else "tile"   # "cols": the column-owner kernel (conv_cols.hip)
+            # "cols": the column-owner kernel (conv_cols.hip), "wave": the wave-private one, "forced-rounds": rounds wherever instantiated
+            os.environ["SEI_CONV_KERNEL"] = {"cols": "cols", "wave": "wave", "forced-rounds": "rounds"}.get(plan, "tile")
             os.environ["SEI_TILE_ROUNDS"] = "1" if plan.startswith("rounds") else "0"   # conv_round_mfma_kernel (two-offset rounds)
-            os.environ.pop("SEI_ROUND_JIT", None)
             if plan in ("rounds+jit", "rounds-jit"):      # force / forbid the refilled-fragment form
                 os.environ["SEI_ROUND_JIT"] = "1" if plan == "rounds+jit" else "0"
-            if plan in ("default", "cols") or plan.startswith("rounds"):
+            if plan in ("default", "cols", "wave", "forced-rounds") or plan.startswith("rounds"):
                 os.environ.pop("SEI_FWD_PLAN", None)
             else:
                 os.environ["SEI_FWD_PLAN"] = plan
