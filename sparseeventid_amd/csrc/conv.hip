@@ -142,8 +142,8 @@ struct DwOps {
 };
 
 // Operand values of T 16-channel tiles for one rule row, with as few (wide) loads as possible: the tiles of a
-// group of 4 (2) interleave their channels -- tile j of the group, row/column r  <->  channel 4r+j (2r+j) -- so
-// lane r16 finds the values of 4 (2) tiles in ONE global_load_dwordx4 (dwordx2).  dw_chan is the inverse map.
+// group of 4 (3, 2) interleave their channels -- tile j of the group, row/column r  <->  channel 4r+j (3r+j, 2r+j) -- so
+// lane r16 finds the values of 4 (3, 2) tiles in ONE global_load_dwordx4 (dwordx3, dwordx2).  dw_chan is the inverse map.
 template <int T>
 __device__ __forceinline__ void dw_load_vec(const float *__restrict__ p, int r16, bool ok, float (&o)[T]) {
     constexpr int B4 = T / 4, REM = T % 4;
@@ -153,12 +153,16 @@ __device__ __forceinline__ void dw_load_vec(const float *__restrict__ p, int r16
         o[4 * q + 0] = ok ? v.x : 0.f; o[4 * q + 1] = ok ? v.y : 0.f;
         o[4 * q + 2] = ok ? v.z : 0.f; o[4 * q + 3] = ok ? v.w : 0.f;
     }
-    if (REM >= 2) {
+    if (REM == 3) {   // three tiles in ONE global_load_dwordx3: tile j, row/column r <-> channel 3r+j
+        struct F3 { float x, y, z; };
+        const F3 v = *reinterpret_cast<const F3 *>(p + 64 * B4 + 3 * r16);
+        o[4 * B4 + 0] = ok ? v.x : 0.f; o[4 * B4 + 1] = ok ? v.y : 0.f; o[4 * B4 + 2] = ok ? v.z : 0.f;
+    }
+    if (REM == 2) {
         const float2 v = *reinterpret_cast<const float2 *>(p + 64 * B4 + 2 * r16);
         o[4 * B4 + 0] = ok ? v.x : 0.f; o[4 * B4 + 1] = ok ? v.y : 0.f;
     }
     if (REM == 1) { const float v = p[64 * B4 + r16]; o[4 * B4] = ok ? v : 0.f; }
-    if (REM == 3) { const float v = p[64 * B4 + 32 + r16]; o[4 * B4 + 2] = ok ? v : 0.f; }
 }
 
 template <int T>
@@ -166,8 +170,9 @@ __device__ __forceinline__ int dw_chan(int t, int r) {  // channel (relative to 
     constexpr int B4 = T / 4, REM = T % 4;
     if (t < 4 * B4) return 64 * (t / 4) + 4 * r + (t % 4);
     const int t2 = t - 4 * B4;
-    if (REM >= 2 && t2 < 2) return 64 * B4 + 2 * r + t2;
-    return 64 * B4 + (REM == 3 ? 32 : 0) + r;
+    if (REM == 3) return 64 * B4 + 3 * r + t2;
+    if (REM == 2) return 64 * B4 + 2 * r + t2;
+    return 64 * B4 + r;
 }
 
 // operands of MFMA step q (rules 4q..4q+3 of the sub-chunk): lane (g, r16) holds X[src_g][ci0 + dw_chan<MT>(m, r16)],

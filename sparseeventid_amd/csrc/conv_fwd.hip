@@ -834,14 +834,14 @@ static ConvPlan plan_tile(int nIn, int nOut, int K, int64_t n_dst) {
         p.slj = (nIn % 32 == 0) ? 2 : 1;
         const int kind_forced = forced_conv_kernel();
         if (nOut == 96 || ((nOut == 128 || nOut == 160) && (n_dst >= 100000 || kind_forced == CONV_KERNEL_ROUNDS)) ||
-            (nOut == 64 && kind_forced == CONV_KERNEL_ROUNDS)) {
+            ((nOut == 64 || nOut == 192) && kind_forced == CONV_KERNEL_ROUNDS)) {
             // 96 / 128 / 160 columns: eight-wave workgroups -- one sub-chunk per wave and offset on 128-row tiles, two
             // column blocks, 16-plane weight slices: 30-50 KB of LDS and 60-90 VGPRs (no spills), three or four
             // workgroups (24-32 waves) per CU.  A phase is one latency chain (barrier -> B from LDS -> MFMA -> LDS
             // add) with little MFMA content; more independent chains per CU is what raises the MFMA rate: 74.4 vs
             // 69.1 TFLOP/s at 96 columns, 82.7 vs 82.1 at 128, 78.0 vs 76.7 at 160 (64-event batch, one device each;
             // profiles/r02_conv_units_experiment.log); 192 columns (level 5, few tiles): slower, not used.
-            p.nw = 8; p.maxs = 1; p.slj = 1; p.blocks = nOut == 64 ? 1 : 2;
+            p.nw = 8; p.maxs = 1; p.slj = 1; p.blocks = nOut == 64 ? 1 : (nOut == 192 ? 3 : 2);
             if (nOut == 96 && nIn % 32 == 0) {
                 // [r3] 96 columns in ONE block with 32-plane weight slices: the same speed within noise (75.0 vs 75.3 TFLOP/s
                 // at level 2, 359.0 vs 359.3 ms per step on one box) but every src row is gathered once instead of once per
