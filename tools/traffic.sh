@@ -21,7 +21,7 @@ def load(d, name):
 fa, fc = load("gpurun_out/traffic/f", "FETCH_SIZE")
 wa, wc = load("gpurun_out/traffic/w", "WRITE_SIZE")
 # FETCH_SIZE / WRITE_SIZE are reported in KiB by rocprofv3's derived metric
-conv = [k for k in fa if "conv_tile_mfma_kernel" in k or "conv_wave_mfma_kernel" in k or "conv_band_mfma_kernel" in k]
+conv = [k for k in fa if any(n in k for n in ("conv_tile_mfma_kernel", "conv_round_mfma_kernel", "conv_wave_mfma_kernel", "conv_band_mfma_kernel"))]
 dw = [k for k in fa if "conv_dw_mfma_kernel" in k]
 def per_launch(keys):
     n = sum(fc[k] for k in keys)
@@ -31,7 +31,7 @@ nd, fd, wd = per_launch(dw)
 res = {"commit": os.environ.get("SEI_COMMIT"),
        "source": "tools/traffic.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 1 --warmup 1 --cpu-events 0 --no-prof",
        "workload": "dune3d train 64 events x 50000 voxels 900^3 tracks",
-       "kernel": "conv_band_mfma_kernel + conv_tile_mfma_kernel + conv_wave_mfma_kernel (all forward + dX launches)",
+       "kernel": "conv_round_mfma_kernel + conv_tile_mfma_kernel + conv_wave_mfma_kernel (all forward + dX launches)",
        "launches": n, "fetch_size_bytes_per_launch": f, "write_size_bytes_per_launch": w,
        "correction": "gfx950 FETCH_SIZE reports 1/2 of the bytes of wide coalesced reads: traffic = 2*FETCH_SIZE + WRITE_SIZE (an upper bound: the 64-B row segments of the gathers may be counted exactly)",
        "traffic_bytes_per_launch": 2 * f + w,
