@@ -481,6 +481,9 @@ __global__ __launch_bounds__(64 * NW, (NJ > 0 ? 4 : occ8_for(NT, 1, 2, 1))) void
         return v;
     };
     auto stage = [&](const Round &r, int s, int buf) {
+#ifdef SEI_ABL_NODMA   // diagnostic: the weight slices are never staged (results wrong, timing only)
+        if (r.q0 >= 0) return;
+#endif
         float *dst = wbuf + (size_t)buf * 2 * SL * COUT;
         stage_slice<PIECES, NW>(W + ((size_t)r.a * CIN + (size_t)s * SL) * COUT, dst, wave, lane);
         if (r.b != r.a) stage_slice<PIECES, NW>(W + ((size_t)r.b * CIN + (size_t)s * SL) * COUT, dst + SL * COUT, wave, lane);
@@ -499,6 +502,13 @@ __global__ __launch_bounds__(64 * NW, (NJ > 0 ? 4 : occ8_for(NT, 1, 2, 1))) void
         // tile rows += partial sums of the sub-chunk a wave held (d4: its packed dst rows, nv: rule slots in it)
         f32x4 acc[1][NT];
         auto rmw = [&](uint32_t d4, int nv) {
+#ifdef SEI_ABL_NORMW   // diagnostic: the sums are not added into the LDS tile (results wrong, timing only)
+            if (d4 != 0xFFFFFFFFu) {
+#pragma unroll
+                for (int nn = 0; nn < NT; nn++) asm volatile("" ::"v"(acc[0][nn]));
+                return;
+            }
+#endif
             float *prow[4];
 #pragma unroll
             for (int i = 0; i < 4; i++) prow[i] = acc_tile + ((d4 >> (8 * i)) & 0xFF) * COUT + r16;

@@ -40,7 +40,8 @@ def main():
     for rnd in range(a.rounds):        # plans interleaved over several rounds: clocks drift during a run
         for plan in a.plans:
             # "cols": the column-owner kernel (conv_cols.hip), "wave": the wave-private one, "forced-rounds": rounds wherever instantiated
-            os.environ["SEI_CONV_KERNEL"] = {"cols": "cols", "wave": "wave", "forced-rounds": "rounds"}.get(plan, "tile")
+            # "default" = the tile kernel with one offset per phase (forced kind 1); every "rounds*" plan forces the round form
+            os.environ["SEI_CONV_KERNEL"] = {"cols": "cols", "wave": "wave"}.get(plan, "rounds" if "rounds" in plan else "tile")
             os.environ["SEI_TILE_ROUNDS"] = "1" if plan.startswith("rounds") else "0"   # conv_round_mfma_kernel (two-offset rounds)
             if plan in ("rounds+jit", "rounds-jit"):      # force / forbid the refilled-fragment form
                 os.environ["SEI_ROUND_JIT"] = "1" if plan == "rounds+jit" else "0"
