@@ -400,10 +400,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? occ8_for(NT, CS, SLJ, MAXS) : o
 // consecutive (nonempty) offsets a < b: wave w takes sub-chunk q0 + w and reads its B operands from the weight slice of the
 // offset that sub-chunk belongs to.  Both offsets' 16-plane slices are staged per phase (2 offsets x 2 buffers x 16 x COUT
 // floats: the LDS of one double-buffered 32-plane slice), a round is nIn / 16 phases, and a round that cannot be filled
-// from two offsets is cut short (never three: the LDS holds two).  The sums keep their order: a sub-chunk is still one
-// MFMA chain over the input planes added to the tile once, and inside a round the sub-chunks of a are added before those of
-// b (one extra barrier per round that holds both); rows of one offset are distinct, so results are bit-identical to the
-// kernel above.
+// from two offsets is cut short (never three: a third slice to stage per phase costs more than its fill returns,
+// profiles/r04_conv_round_ab.log).  The sums keep their order: a sub-chunk is still one MFMA chain over the input planes
+// added to the tile once, and the sub-chunks of a are added before those of b (which wait for the next round's first
+// barrier, see round_begin); rows of one offset are distinct, so results are bit-identical to the kernel above.
 template <class F, int... S>
 __device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, S...>) {
     (f(std::integral_constant<int, S>{}), ...);
@@ -419,11 +419,10 @@ struct Round {
     int ea;
 };
 
-// NJ > 0: nIn == 16 NJ and the A fragments of a wave's NEXT sub-chunk (all NJ slices) are gathered in one burst during the
-// first phase of the current round, behind that phase's slice request: memory operations retire in order, so a gather
-// requested per phase (NJ == 0, as in the kernel above) has ONE phase to land before the next barrier's vmcnt wait needs the
-// slice behind it -- with 16-plane slices a phase is shorter than a gather's latency, every phase waited for one.  The burst
-// has two phases, and the four phases after them wait for L2-resident weight slices only.
+// NJ == 0: the A fragment of the next phase is gathered per phase, as in the kernel above.  Memory operations retire in order,
+// so that gather has ONE phase to land before the next barrier's vmcnt wait can see the weight slice requested behind it --
+// and a 16-plane phase is shorter than a gather's latency: every phase waits for one.  NJ > 0 (nIn == 16 NJ): the fragments
+// of a sub-chunk live in ONE register set that is refilled a phase after use (see the loop): two phases to land.
 template <int NT, int NW, int NJ>
 __global__ __launch_bounds__(64 * NW, (NJ > 0 ? 4 : occ8_for(NT, 1, 2, 1))) void conv_round_mfma_kernel(
     const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ Y,
