@@ -65,6 +65,22 @@ def test_residual_block_inference_is_bit_identical_to_the_two_pass_eval_path(C):
     assert float(one.abs().max()) > 0 and bool((one < 0).any())      # LeakyReLU really applied to both signs
 
 
+@pytest.mark.parametrize("C", [64, 128, 160, 192])
+def test_residual_block_inference_through_the_round_kernel(C, force_conv_kernel):
+    """The two-offset-round form of the tile kernel applies the same epilogue; small clouds only reach it when it is pinned
+    (the default takes it for 96 columns at any size, for 128 / 160 from 100 000 rows on)."""
+    from sparseeventid_amd.networks import ResidualBlock
+    t = _cloud(5 + C, 3, [28, 26, 30], 2200, C)
+    torch.manual_seed(C)
+    blk = ResidualBlock(nIn=C, nOut=C, dim=3, params=_params()).cuda()
+    _randomise_bn(blk, C)
+    force_conv_kernel("tile")
+    two_tile, one_tile = _both_ways(blk, t)
+    force_conv_kernel("rounds")
+    two, one = _both_ways(blk, t)
+    assert torch.equal(two, one) and torch.equal(one, one_tile) and torch.equal(two, two_tile)
+
+
 def test_stem_block_and_downsample_inference():
     """1 -> 32 planes 5^3 (the small-nIn kernel) and the strided 2^3 convolution 64 -> 96 (tile kernel, K = 8)."""
     import sparseeventid_amd.scn as scn
