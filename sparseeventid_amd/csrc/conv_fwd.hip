@@ -423,14 +423,16 @@ struct Round {
 // so that gather has ONE phase to land before the next barrier's vmcnt wait can see the weight slice requested behind it --
 // and a 16-plane phase is shorter than a gather's latency: every phase waits for one.  NJ > 0 (nIn == 16 NJ): the fragments
 // of a sub-chunk live in ONE register set that is refilled a phase after use (see the loop): two phases to land.
-template <int NT, int NW, int NJ>
+// SLJ: a slice is 16 SLJ input planes (the refilled form groups SLJ fragments per phase; the per-phase form takes SLJ == 1)
+template <int NT, int NW, int NJ, int SLJ = 1>
 __global__ __launch_bounds__(64 * NW, (NJ > 0 ? 4 : occ8_for(NT, 1, 2, 1))) void conv_round_mfma_kernel(
     const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ Y,
     const int32_t *__restrict__ tile_sub_start, const int32_t *__restrict__ tile_seg,
     const int32_t *__restrict__ sub_src, const uint8_t *__restrict__ sub_dst, int64_t n_dst, int K, int CIN, int n_tiles,
     const float *__restrict__ init, int ldy, int blocks, double *__restrict__ stats, ConvEpilogue ep) {
     extern __shared__ float lds[];
-    constexpr int TR = 16 * NW, SL = 16, COUT = NT * 16, PIECES = SL * COUT / 256;
+    static_assert(SLJ == 1 || (NJ > 0 && NJ % SLJ == 0), "wider slices: refilled form only");
+    constexpr int TR = 16 * NW, SL = 16 * SLJ, COUT = NT * 16, PIECES = SL * COUT / 256;
     const int vid = xcd_item(n_tiles * blocks);
     if (vid >= n_tiles * blocks) return;
     const int tile = vid / blocks, cblk = vid - tile * blocks;
@@ -493,10 +495,13 @@ __global__ __launch_bounds__(64 * NW, (NJ > 0 ? 4 : occ8_for(NT, 1, 2, 1))) void
         Round r0 = plan(0, 0), r1 = plan(r0.q1, r0.b), r2 = plan(r1.q1, r1.b);
         Idx ic = load_idx(r0), i1 = load_idx(r1), i2 = load_idx(r2);
         stage(r0, 0, 0);
-        constexpr int NA = NJ > 0 ? NJ : 1;
-        float4 a_c[NA][1][1], a_n[1][1][1];
+        constexpr int NA = NJ > 0 ? NJ / SLJ : 1;   // phases of a round in the refilled form
+        float4 a_c[NA][1][SLJ], a_n[1][1][1];
 #pragma unroll
-        for (int j = 0; j < NA; j++) a_c[j][0][0] = load_a(X, r0.q0 + wave < r0.q1 ? ic.src : -1, CIN, 16 * j + 4 * g);
+        for (int j = 0; j < NA; j++)
+#pragma unroll
+            for (int jj = 0; jj < SLJ; jj++)
+                a_c[j][0][jj] = load_a(X, r0.q0 + wave < r0.q1 ? ic.src : -1, CIN, 16 * (SLJ * j + jj) + 4 * g);
         int phase = 0;
         // tile rows += partial sums of the sub-chunk a wave held (d4: its packed dst rows, nv: rule slots in it)
         f32x4 acc[1][NT];
@@ -542,35 +547,42 @@ __global__ __launch_bounds__(64 * NW, (NJ > 0 ? 4 : occ8_for(NT, 1, 2, 1))) void
             Round r3 = r2;
             Idx i3 = i2;
             if constexpr (NJ > 0) {
-                static_assert(NJ == 0 || NJ >= 4, "the schedule below uses phases 0..3");
-                // ONE set of A fragments: a_c[s] holds slice s of the wave's current sub-chunk until phase s has used it and is
-                // refilled in the NEXT phase -- with slice s of the next round's sub-chunk (slice NJ-1: of the current one, it is
-                // used last) -- so a gather has NJ-1 phases to be used and, memory operations retiring in order, two phases to land
-                // (the barrier of phase p+2 waits for the slice requested in phase p+1, which sits behind it in the queue).
-                // Queue of one phase: [slice a][slice b][gather]([index loads x 2] in phase 2).
-                static_for<NJ>([&](auto sc) {
+                constexpr int NP = NJ / SLJ;          // phases of a round
+                constexpr int IDXP = NP >= 4 ? 2 : 1; // the phase that requests the index words of round r + 3
+                static_assert(NJ == 0 || NP >= 3, "the schedule below uses three phases");
+                // ONE set of A fragments: a_c[s] holds the SLJ fragments of phase s of the wave's current sub-chunk until that
+                // phase has used them and is refilled in the NEXT phase -- with those of phase s of the next round's sub-chunk
+                // (phase NP-1: of the current one, it is used last) -- so a gather has NP-1 phases to be used and, memory
+                // operations retiring in order, two phases to land (the barrier of phase p+2 waits for the slice requested in
+                // phase p+1, which sits behind it in the queue).
+                // Queue of one phase: [slice a][slice b][SLJ gathers]([index loads x 2] in phase IDXP).
+                static_for<NP>([&](auto sc) {
                     constexpr int s = decltype(sc)::value;
                     if (phase == 0)
                         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" SEI_BARRIER_INSN ::: "memory");
-                    else if (s == 3)
-                        asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\t" SEI_BARRIER_INSN ::: "memory");
+                    else if (s == (IDXP + 1) % NP)
+                        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\t" SEI_BARRIER_INSN ::"n"(SLJ + 2) : "memory");
                     else
-                        asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\t" SEI_BARRIER_INSN ::: "memory");
+                        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\t" SEI_BARRIER_INSN ::"n"(SLJ) : "memory");
                     TRACE(0);
                     if (s == 0) round_begin();
                     {
-                        // the gather of two phases ago (into a_c[s-3]) is in: tell hipcc here, so that it plants no wait of its own
-                        constexpr int jg = (s + NJ - 3) % NJ;
-                        asm volatile("" : "+v"(a_c[jg][0][0].x), "+v"(a_c[jg][0][0].y), "+v"(a_c[jg][0][0].z), "+v"(a_c[jg][0][0].w));
+                        // the gathers of two phases ago (into a_c[s-3]) are in: tell hipcc here, so that it plants no wait of its own
+                        constexpr int jg = (s + 3 * NP - 3) % NP;
+#pragma unroll
+                        for (int jj = 0; jj < SLJ; jj++)
+                            asm volatile("" : "+v"(a_c[jg][0][jj].x), "+v"(a_c[jg][0][jj].y), "+v"(a_c[jg][0][jj].z), "+v"(a_c[jg][0][jj].w));
                     }
-                    const bool same = s + 1 < NJ;
+                    const bool same = s + 1 < NP;
                     stage(same ? r0 : r1, same ? s + 1 : 0, (phase + 1) & 1);
                     {
-                        constexpr int jr = (s + NJ - 1) % NJ;   // the fragment the previous phase used
-                        a_c[jr][0][0] = load_a(X, s == 0 ? rowc : rown, CIN, 16 * jr + 4 * g);
+                        constexpr int jr = (s + NP - 1) % NP;   // the fragments the previous phase used
+#pragma unroll
+                        for (int jj = 0; jj < SLJ; jj++)
+                            a_c[jr][0][jj] = load_a(X, s == 0 ? rowc : rown, CIN, 16 * (SLJ * jr + jj) + 4 * g);
                         asm volatile("" ::: "memory");
                     }
-                    if (s == 2) {
+                    if (s == IDXP) {
                         // the index words of round r + 3 are requested mid-round into registers of their own and move over at
                         // the end of the round, long after they have arrived (requested at the end of the round, hipcc loaded
                         // them into spare registers and waited vmcnt(0) for the copy right there)
@@ -580,7 +592,7 @@ __global__ __launch_bounds__(64 * NW, (NJ > 0 ? 4 : occ8_for(NT, 1, 2, 1))) void
                     }
                     TRACE(1);
                     if (valid)
-                        compute_phase<NT, 1, 1, 1, COUT>(wbuf + (size_t)((phase & 1) * 2 + in_b) * SL * COUT, a_c[s], acc, g, r16);
+                        compute_phase<NT, SLJ, 1, 1, COUT>(wbuf + (size_t)((phase & 1) * 2 + in_b) * SL * COUT, a_c[s], acc, g, r16);
                     TRACE(2 | ((valid ? 1 : 0) << 2));
                     phase++;
                 });
@@ -817,6 +829,17 @@ static bool env_plan(int nOut, int *maxs, int *cs, int *slj, int *blocks, int *n
 }
 #endif
 
+// sixteen-wave instantiations of the round kernel: slice width / 16 (0: none) for NT column tiles and nIn input planes
+static int round16_slj(int nt, int nIn) {
+    if (nIn % 32 == 0 && nIn >= 96 && nIn <= 192) {
+        if (nt == 6 && (nIn == 96 || nIn == 128)) return 2;
+        if (nt == 4 && (nIn == 96 || nIn == 128 || nIn == 160)) return 2;
+        if (nt == 5 && (nIn == 128 || nIn == 160 || nIn == 192)) return 2;
+    }
+    if (nt == 6 && nIn == 64) return 1;
+    return 0;
+}
+
 static ConvPlan plan_tile(int nIn, int nOut, int K, int64_t n_dst) {
     ConvPlan p{};
     bool mfma = (nIn % 16 == 0) && (nOut % 16 == 0) && nIn >= 16 && nOut <= 256;
@@ -868,7 +891,18 @@ static ConvPlan plan_tile(int nIn, int nOut, int K, int64_t n_dst) {
 #ifdef SEI_EXPERIMENTS
             if (const char *e = getenv("SEI_TILE_ROUNDS")) on = atoi(e) != 0;
 #endif
-            if (on) { p.g = 2; p.slj = 2; }
+            if (on) {
+                p.g = 2; p.slj = 2;
+                // [r4, late] where instantiated: ONE sixteen-wave workgroup per CU on 256-row tiles (the variant dW walks anyway)
+                // with 32-plane slices -- half the phases, half the weight staging per sub-chunk, padding 0.95 instead of 0.90:
+                // 88.1 / 92.9 / 89.0 against 84.7 / 86.4 / 86.6 TFLOP/s at 96 / 128 / 160 planes (profiles/r04_conv_round_ab.log)
+                const int cols = nOut / p.blocks;
+                bool wide = round16_slj(cols / 16, nIn) > 0;
+#ifdef SEI_EXPERIMENTS
+                if (const char *e = getenv("SEI_ROUND_NW")) wide = wide && atoi(e) == 16;
+#endif
+                if (wide) { p.nw = 16; p.slj = 2 * round16_slj(cols / 16, nIn); }
+            }
         }
 #ifdef SEI_EXPERIMENTS
         int em, ec, es, eb, ew;
@@ -923,6 +957,22 @@ static int launch_round(const TiledRules &t, const ConvPlan &p, const float *X, 
                         int nIn, const float *init, double *stats, hipStream_t st, const ConvEpilogue &ep) {
     // one register set of A fragments refilled a phase after use (NJ = nIn / 16 > 0) where 128 registers hold it; the narrower
     // column blocks keep the per-phase gathers and three workgroups per CU
+    if (p.nw == 16) {   // one sixteen-wave workgroup per CU, refilled fragments, 32-plane slices (16-plane behind 64 planes)
+#define ROUND16(NJ_, SLJ_)                                                                                               \
+        if (nIn == 16 * NJ_ && p.slj == 2 * SLJ_) {                                                                      \
+            SEI_TRY(ensure_max_lds((const void *)conv_round_mfma_kernel<NT, 16, NJ_, SLJ_>, 160 * 1024));                \
+            conv_round_mfma_kernel<NT, 16, NJ_, SLJ_><<<((t.n_tiles * p.blocks + 7) / 8) * 8, 1024, p.lds_bytes, st>>>(  \
+                X, W, bias, Y, t.tile_sub_start, t.tile_seg, t.sub_src, t.sub_dst, t.n_dst, t.K, nIn, t.n_tiles, init,   \
+                NT * 16 * p.blocks, p.blocks, stats, ep);                                                                \
+            SEI_LAUNCH_CHECK();                                                                                          \
+            return 0;                                                                                                    \
+        }
+        if constexpr (NT == 6) { ROUND16(6, 2) ROUND16(8, 2) ROUND16(4, 1) }
+        if constexpr (NT == 4) { ROUND16(6, 2) ROUND16(8, 2) ROUND16(10, 2) }
+        if constexpr (NT == 5) { ROUND16(8, 2) ROUND16(10, 2) ROUND16(12, 2) }
+#undef ROUND16
+        SEI_FAIL("conv_forward: no sixteen-wave round instantiation for this plan");
+    }
     bool jit = NT == 6 || NT == 5;
 #ifdef SEI_EXPERIMENTS
     if (const char *e = getenv("SEI_ROUND_JIT")) jit = atoi(e) != 0;
