@@ -833,7 +833,7 @@ static bool env_plan(int nOut, int *maxs, int *cs, int *slj, int *blocks, int *n
 static int round16_slj(int nt, int nIn) {
     if (nIn % 32 == 0 && nIn >= 96 && nIn <= 192) {
         if (nt == 6 && (nIn == 96 || nIn == 128)) return 2;
-        if (nt == 4 && (nIn == 96 || nIn == 128 || nIn == 160)) return 2;
+        if (nt == 4 && (nIn == 96 || nIn == 128 || nIn == 160 || nIn == 192)) return 2;
         if (nt == 5 && (nIn == 128 || nIn == 160 || nIn == 192)) return 2;
     }
     if (nt == 6 && nIn == 64) return 1;
@@ -865,8 +865,13 @@ static ConvPlan plan_tile(int nIn, int nOut, int K, int64_t n_dst) {
         }
         p.slj = (nIn % 32 == 0) ? 2 : 1;
         const int kind_forced = forced_conv_kernel();
+        // [r4, late] 192 columns (3 x 64) join from 30 000 rows on: sixteen-wave rounds 83.1 against 69.6 TFLOP/s at level 5 of the
+        // 64-event batch (42 666 rows: 501 workgroups), 317.9 -> 316.9 ms per step.  64 -> 64 columns do NOT: eight-wave rounds run
+        // 64.0 against the wave kernel's 62.2 TFLOP/s at level 1 alone, but the whole step loses 1.6 ms with them (318.5 vs 316.9 ms,
+        // builds interleaved twice on one box) -- they stay behind sei_debug_force_conv_kernel(5)
         if (nOut == 96 || ((nOut == 128 || nOut == 160) && (n_dst >= 100000 || kind_forced == CONV_KERNEL_ROUNDS)) ||
-            ((nOut == 64 || nOut == 192) && kind_forced == CONV_KERNEL_ROUNDS)) {
+            (nOut == 192 && (n_dst >= 30000 || kind_forced == CONV_KERNEL_ROUNDS)) ||
+            (nOut == 64 && kind_forced == CONV_KERNEL_ROUNDS)) {
             // 96 / 128 / 160 columns: eight-wave workgroups -- one sub-chunk per wave and offset on 128-row tiles, two
             // column blocks, 16-plane weight slices: 30-50 KB of LDS and 60-90 VGPRs (no spills), three or four
             // workgroups (24-32 waves) per CU.  A phase is one latency chain (barrier -> B from LDS -> MFMA -> LDS
@@ -968,7 +973,7 @@ static int launch_round(const TiledRules &t, const ConvPlan &p, const float *X, 
             return 0;                                                                                                    \
         }
         if constexpr (NT == 6) { ROUND16(6, 2) ROUND16(8, 2) ROUND16(4, 1) }
-        if constexpr (NT == 4) { ROUND16(6, 2) ROUND16(8, 2) ROUND16(10, 2) }
+        if constexpr (NT == 4) { ROUND16(6, 2) ROUND16(8, 2) ROUND16(10, 2) ROUND16(12, 2) }
         if constexpr (NT == 5) { ROUND16(8, 2) ROUND16(10, 2) ROUND16(12, 2) }
 #undef ROUND16
         SEI_FAIL("conv_forward: no sixteen-wave round instantiation for this plan");

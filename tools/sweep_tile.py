@@ -42,7 +42,7 @@ def main():
             # "cols": the column-owner kernel (conv_cols.hip), "wave": the wave-private one, "forced-rounds": rounds wherever instantiated
             # "default" = the tile kernel with one offset per phase (forced kind 1); every "rounds*" plan forces the round form
             os.environ["SEI_CONV_KERNEL"] = {"cols": "cols", "wave": "wave"}.get(plan, "rounds" if "rounds" in plan else "tile")
-            os.environ["SEI_TILE_ROUNDS"] = "1" if plan.startswith("rounds") else "0"   # conv_round_mfma_kernel (two-offset rounds)
+            os.environ["SEI_TILE_ROUNDS"] = "1" if "rounds" in plan else "0"   # conv_round_mfma_kernel (two-offset rounds)
             for kv in ("SEI_ROUND_JIT", "SEI_ROUND_RING", "SEI_ROUND_SLJ", "SEI_ROUND_NOFF", "SEI_ROUND_NW"):
                 os.environ.pop(kv, None)
             if plan in ("rounds+jit", "rounds-jit"):      # force / forbid the refilled-fragment form
