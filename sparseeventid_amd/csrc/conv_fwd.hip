@@ -865,12 +865,13 @@ static ConvPlan plan_tile(int nIn, int nOut, int K, int64_t n_dst) {
         }
         p.slj = (nIn % 32 == 0) ? 2 : 1;
         const int kind_forced = forced_conv_kernel();
-        // [r4, late] 192 columns (3 x 64) join from 30 000 rows on: sixteen-wave rounds 83.1 against 69.6 TFLOP/s at level 5 of the
-        // 64-event batch (42 666 rows: 501 workgroups), 317.9 -> 316.9 ms per step.  64 -> 64 columns do NOT: eight-wave rounds run
+        // [r4, late] 192 columns (3 x 64) join from 18 000 rows on: sixteen-wave rounds 83.1 against 69.6 TFLOP/s at level 5 of the
+        // 64-event batch (42 666 rows: 501 workgroups), 317.9 -> 316.9 ms per step; 72.1 vs 61.5 at 20 627 rows, 36.4 vs 50.6 at
+        // 10 358 (160 columns: 72.9 vs 73.3 at 71 639 rows, 53.8 vs 64.7 at 35 830 -- their threshold stays at 100 000).  64 -> 64 columns do NOT: eight-wave rounds run
         // 64.0 against the wave kernel's 62.2 TFLOP/s at level 1 alone, but the whole step loses 1.6 ms with them (318.5 vs 316.9 ms,
         // builds interleaved twice on one box) -- they stay behind sei_debug_force_conv_kernel(5)
         if (nOut == 96 || ((nOut == 128 || nOut == 160) && (n_dst >= 100000 || kind_forced == CONV_KERNEL_ROUNDS)) ||
-            (nOut == 192 && (n_dst >= 30000 || kind_forced == CONV_KERNEL_ROUNDS)) ||
+            (nOut == 192 && (n_dst >= 18000 || kind_forced == CONV_KERNEL_ROUNDS)) ||
             (nOut == 64 && kind_forced == CONV_KERNEL_ROUNDS)) {
             // 96 / 128 / 160 columns: eight-wave workgroups -- one sub-chunk per wave and offset on 128-row tiles, two
             // column blocks, 16-plane weight slices: 30-50 KB of LDS and 60-90 VGPRs (no spills), three or four
