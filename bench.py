@@ -95,6 +95,46 @@ def cpu_baseline(arr, labels, image_size, n_events, fwd_only, threads=16, warmup
                          "OpenBLAS from the scipy wheel" if info["blas"] else "plain loops, no BLAS found")}
 
 
+def self_launch(n, one_device, launch_check):
+    """`bench.py --gpus N` without a launcher: start N rank processes through torch.distributed.run (one per GPU, RCCL)
+    and relay what they print.  Returns the launcher's exit code; never prints a line of its own."""
+    import socket
+    import subprocess
+    if not one_device and not launch_check:
+        import torch
+        if torch.cuda.device_count() < n:      # counting does not initialise the GPU
+            print("bench.py: --gpus %d but only %d device(s) visible" % (n, torch.cuda.device_count()), file=sys.stderr)
+            return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def launch_check(args, world, rank):
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group(args.backend, rank=rank, world_size=world)
+    t = torch.tensor([float(rank)])
+    if args.backend == "nccl":
+        torch.cuda.set_device(0 if args.one_device else int(os.environ.get("LOCAL_RANK", "0")))
+        t = t.cuda()
+    dist.all_reduce(t)
+    ok = float(t.item()) == world * (world - 1) / 2
+    if rank == 0:
+        print(json.dumps({"launch_check": ok, "n_gpus": world, "backend": args.backend}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    if not ok:
+        raise SystemExit("launch check: the ranks' sum is wrong")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -130,13 +170,34 @@ def main():
                     "kernel, sei_conv_bn_inference), or 'train': batch statistics under no_grad (rounds 1-2 measured this)")
     ap.add_argument("--no-prefetch", dest="prefetch", action="store_false",
                     help="rulebooks at the top of the forward pass instead (Trainer.batch_rulebooks)")
+    ap.add_argument("--batches", type=int, default=3,
+                    help="distinct pre-staged batches (seeds 64*b + e, SURVEY 8d) cycled through the timed loop; `value` is "
+                    "measured over them, and the same loop over batch 0 alone is reported beside it (single_batch_repeat)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="rendezvous only: every rank joins the process group and all-reduces its rank, rank 0 prints "
+                    '{"launch_check": true, "n_gpus": world}; no GPU work (tests of the self-launcher, runs on CPU with --backend gloo)')
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # Started WITHOUT a launcher: become one.  Nothing here has touched the GPU (counting devices does not initialise
+        # it), the ranks are fresh processes, the parent only relays rank 0's JSON line and the exit code.
+        sys.exit(self_launch(args.gpus, args.one_device, args.launch_check))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world != args.gpus:
+        # never measure a world other than the one asked for (a line with n_gpus != --gpus would void a scaling record)
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node %d, or without a launcher" % (
+            args.gpus, world, args.gpus))
+    if args.launch_check:
+        return launch_check(args, world, rank)
+    if not args.one_device:
+        import torch as _t
+        if _t.cuda.device_count() < world:     # counting does not initialise the GPU
+            raise SystemExit("--gpus %d but only %d device(s) visible (one rank per GPU; --one-device is the rehearsal mode)" % (
+                world, _t.cuda.device_count()))
 
     # synthetic input is generated BEFORE the GPU is touched (fork pool)
     ncpu = os.cpu_count() or 8
@@ -148,7 +209,9 @@ def main():
         grid, args.kind = (3, 2048, 1280), "sbnd"
         if args.voxels == 50000:
             args.voxels = 15000
-    arr, labels = generate_batch(rank, 0, args.batch, grid, args.voxels, args.kind, workers)
+    nb = max(1, args.batches)
+    batches = [generate_batch(rank, b, args.batch, grid, args.voxels, args.kind, workers) for b in range(nb)]
+    arr, labels = batches[0]
 
     import torch
     import torch.distributed as dist
@@ -172,7 +235,9 @@ def main():
     tr = Trainer(image_size=image_size, device="cuda", seed=0, model="sbnd" if args.model == "sbnd" else "resnet")
     tr.arena.broadcast_parameters()
     tr.buffers.broadcast()
-    image, lab = tr.stage(tr.to_scn_input(arr), labels)   # inputs resident in HBM before timing
+    resident = [tr.stage(tr.to_scn_input(a), l) for a, l in batches]   # every batch's inputs resident in HBM before timing
+    images, labs = [x[0] for x in resident], [x[1] for x in resident]
+    image = images[0]
 
     # default: the InputLayer hash and the rulebooks of step i+1 are built on a side stream while step i computes
     # (Trainer.prefetch) -- once per step, inside the timed region: K timed steps consume K builds and issue K builds.
@@ -185,20 +250,20 @@ def main():
     inputs_ready = torch.cuda.Event()
     inputs_ready.record()
     staged = [tr.prefetch(image, after=inputs_ready) if prefetch else image]
+    cur = {"i": 0, "cycle": nb > 1}   # step i trains on batch i % nb (cycle) or on batch 0 (single-batch repeat)
 
     if args.mode == "fwd" and args.fwd_bn == "eval":
         tr.encoder.eval(); tr.head.eval()
 
     def step():
+        b, bn = (cur["i"] % nb, (cur["i"] + 1) % nb) if cur["cycle"] else (0, 0)
         if args.mode == "train":
-            tr.train_step(staged[0], lab)
-            if prefetch:
-                staged[0] = tr.prefetch(image, after=inputs_ready)
+            tr.train_step(staged[0], labs[b])
         else:
             with torch.no_grad():
                 tr.forward(staged[0])
-            if prefetch:
-                staged[0] = tr.prefetch(image, after=inputs_ready)
+        staged[0] = tr.prefetch(images[bn], after=inputs_ready) if prefetch else images[bn]
+        cur["i"] += 1
 
     def fence():
         torch.cuda.synchronize()
@@ -211,9 +276,17 @@ def main():
         from sparseeventid_amd import scn
         scn.set_backward_streams(args.overlap_backward)
     shared = bool(args.overlap_backward) and args.mode == "train"   # dX launches share the GPU with dW launches
+    import ctypes
+
+    def pool_held_now():
+        h, u = ctypes.c_int64(), ctypes.c_int64()
+        lib.sei_pool_stats(ctypes.byref(h), ctypes.byref(u))
+        return h.value
+
     for _ in range(args.warmup):
         step()
     fence()
+    pool_warm = pool_held_now()
     if not args.no_prof:
         lib.sei_prof_reset()
         lib.sei_prof_enable(1)
@@ -223,12 +296,26 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     lib.sei_prof_enable(0)
+    pool_end = pool_held_now()
+    single = None
+    if nb > 1:
+        # the same loop on ONE batch (what rounds 1-4 reported as `value`): identical sizes every step
+        cur["cycle"] = False
+        staged[0] = tr.prefetch(images[0], after=inputs_ready) if prefetch else images[0]
+        step()
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        single = (time.perf_counter() - t1) / args.steps * 1e3
     ms = dt / args.steps * 1e3
     sync = None
     if grouped:
-        t = torch.tensor([ms], device="cuda", dtype=torch.float64)
+        t = torch.tensor([ms, single or 0.0], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        ms = float(t.item())
+        ms = float(t[0].item())
+        single = float(t[1].item()) if single is not None else None
         # data-parallel invariants, checked AFTER the timed region: every rank ended with bit-identical parameters
         # (elementwise max == min over ranks) and every rank trained on a different batch
         if args.mode == "train":
@@ -283,10 +370,7 @@ def main():
         staging = {"ms_per_step": ms2, "events_per_s": args.batch / (ms2 * 1e-3), "steps": k2,
                    "path": "pinned host larcv fp32 [B,1,M,4] -> H2D -> sei_larcv_to_scn on the device (copy stream, one batch ahead) -> train step"}
 
-    import ctypes
-    _h, _u = ctypes.c_int64(), ctypes.c_int64()
-    lib.sei_pool_stats(ctypes.byref(_h), ctypes.byref(_u))
-    pool_held = _h.value
+    pool_held = pool_held_now()
     if rank == 0:
         roof = None
         if not args.no_prof:
@@ -391,6 +475,17 @@ def main():
                             # the library's own device pool (hash tables, rulebooks, scratch): bytes held at the end
                             "library_pool_held": pool_held / 1e9},
         }
+        out["batches"] = {
+            "distinct_batches_cycled": nb, "seeds": "1000003*rank + 64*b + e, b = 0..%d" % (nb - 1),
+            # the same K steps on batch 0 alone (identical sizes every step: the quantity rounds 1-4 reported)
+            "single_batch_repeat": None if single is None else {"ms_per_step": single, "events_per_s": args.batch * world / (single * 1e-3)},
+            # bytes the library's device pool holds after the warm-up steps and after the timed loop: a pool that still
+            # grows while the batches repeat would show here (warm-up must have seen every batch: warmup >= batches)
+            "library_pool_held_after_warmup": pool_warm, "library_pool_held_after_timed_loop": pool_end,
+            "library_pool_stopped_growing": (pool_end <= pool_warm) if args.warmup >= nb else None}
+        if args.warmup >= nb and pool_end > pool_warm:
+            print("bench.py: WARNING the library's device pool grew by %.1f MB during the timed loop" % ((pool_end - pool_warm) / 1e6),
+                  file=sys.stderr)
         if sync is not None:
             out["data_parallel_checks"] = sync
         if staging is not None:

@@ -404,6 +404,7 @@ int sei_level_rows(sei_metadata_t *m, const int32_t spatial[3], int64_t *n_rows)
     std::lock_guard<std::mutex> lk(m->mu);
     Level *l = find_level(m, spatial);
     if (!l) SEI_FAIL("no level with this spatial size in the metadata");
+    if (l->failed) SEI_FAIL("the discovery of this level failed earlier (hash table full or a lost synchronisation)");
     *n_rows = l->n;
     return 0;
 }
@@ -437,6 +438,7 @@ int sei_subm_rulebook(sei_metadata_t *m, const int32_t spatial[3], const int32_t
         }
     Level *l = find_level(m, spatial);
     if (!l) SEI_FAIL("SubmanifoldConvolution: no level with this spatial size in the metadata");
+    if (l->failed) SEI_FAIL("SubmanifoldConvolution: the discovery of this level failed earlier (hash table full or a lost synchronisation)");
     for (int d = 0; d < 3; d++)
         if (filter[d] < 1 || filter[d] % 2 == 0) SEI_FAIL("SubmanifoldConvolution: filter sizes must be odd");
     sei_rulebook *rb = new sei_rulebook();
@@ -463,19 +465,34 @@ int sei_subm_rulebook(sei_metadata_t *m, const int32_t spatial[3], const int32_t
 }
 
 // scn.Convolution's rulebook: finds it, or creates it and BEGINS the discovery of its output level (build_strided_level_begin:
-// nothing synchronised yet; *pl says whether a finish is owed)
+// nothing synchronised yet; *pl says whether a finish is owed).
+// Returns CHAIN_BREAK (nothing created) when the input level is itself unfinished AND an input row may yield more than one
+// candidate site (overlapping filter, e.g. size 3 / stride 2: 8): the level would be sized by the input's UPPER BOUND times
+// that factor, which compounds along a chain (50 k points -> 400 k -> 3.2 M -> 25 M -> 205 M candidates; round-4 advisor).
+// The caller then synchronises, finishes what is pending and calls again: the level is sized from the exact row count.
+// size == stride (factor 1, every network of the reference) chains freely: its bound never exceeds the input points.
+constexpr int CHAIN_BREAK = 2;
 static int conv_rulebook_begin(sei_metadata_t *m, const int32_t spatial_in[3], const int32_t size[3], const int32_t stride[3],
-                               hipStream_t st, sei_rulebook_t **rb_out, int32_t spatial_out[3], PendingLevel *pl) {
+                               hipStream_t st, sei_rulebook_t **rb_out, int32_t spatial_out[3], PendingLevel *pl,
+                               bool may_break = false) {
     *pl = PendingLevel();
     std::lock_guard<std::mutex> lk(m->mu);
     for (auto *rb : m->rulebooks)
         if (!rb->submanifold && same3(rb->spatial_in, spatial_in) && same3(rb->size, size) && same3(rb->stride, stride)) {
+            if (rb->lout && rb->lout->failed) SEI_FAIL("Convolution: the discovery of this rulebook's output level failed earlier (hash table full or a lost synchronisation)");
             *rb_out = rb;
             for (int d = 0; d < 3; d++) spatial_out[d] = rb->spatial_out[d];
             return 0;
         }
     Level *l = find_level(m, spatial_in);
     if (!l) SEI_FAIL("Convolution: no level with this spatial size in the metadata");
+    if (l->failed) SEI_FAIL("Convolution: the discovery of the input level failed earlier (hash table full or a lost synchronisation)");
+    if (may_break && l->n_dev) {
+        int mult = 1;
+        for (int d = 0; d < 3; d++)
+            if (size[d] >= 1 && stride[d] >= 1) mult *= (size[d] + stride[d] - 1) / stride[d];
+        if (mult > 1) return CHAIN_BREAK;
+    }
     sei_rulebook *rb = new sei_rulebook();
     rb->submanifold = false;
     for (int d = 0; d < 3; d++) {
@@ -498,7 +515,10 @@ int sei_conv_rulebook(sei_metadata_t *m, const int32_t spatial_in[3], const int3
                       sei_stream_t stream, sei_rulebook_t **rb_out, int32_t spatial_out[3]) {
     PendingLevel pl;
     SEI_TRY(conv_rulebook_begin(m, spatial_in, size, stride, (hipStream_t)stream, rb_out, spatial_out, &pl));
-    if (pl.pending && sync_stream((hipStream_t)stream) != hipSuccess) SEI_FAIL("rulebook: hipStreamSynchronize failed");
+    if (pl.pending && sync_stream((hipStream_t)stream) != hipSuccess) {
+        build_strided_level_abort(&pl);   // the half-built level stays registered but marked failed: later lookups report it
+        SEI_FAIL("rulebook: hipStreamSynchronize failed");
+    }
     return build_strided_level_finish(&pl);
 }
 
@@ -531,8 +551,11 @@ std::vector<LikeItem> like_items(sei_metadata_t *like) {
 // Every rulebook of the list, the strided ones only BEGUN: a level discovered behind an unfinished one reads that one's row
 // count from the device, so the whole chain of levels is queued back to back; the caller synchronises ONCE and finishes
 // them (finish_levels).  Stops at the first failure (a level of the template that does not exist for this batch).
+// `flush`: synchronises the stream and finishes everything begun so far (the caller's pending input level and `levels`);
+// called where a chain must not go on from an upper bound (conv_rulebook_begin: CHAIN_BREAK).
+template <class Flush>
 int begin_rulebooks(sei_metadata_t *m, const std::vector<LikeItem> &items, hipStream_t st, std::vector<sei_rulebook_t *> *made,
-                    std::vector<PendingLevel> *levels) {
+                    std::vector<PendingLevel> *levels, Flush &&flush) {
     made->assign(items.size(), nullptr);
     for (size_t i = 0; i < items.size(); i++) {
         const LikeItem &it = items[i];
@@ -541,7 +564,12 @@ int begin_rulebooks(sei_metadata_t *m, const std::vector<LikeItem> &items, hipSt
             SEI_TRY(sei_subm_rulebook(m, it.sp, it.size, (sei_stream_t)st, &(*made)[i]));
         } else {
             PendingLevel pl;
-            SEI_TRY(conv_rulebook_begin(m, it.sp, it.size, it.stride, st, &(*made)[i], spo, &pl));
+            int rc = conv_rulebook_begin(m, it.sp, it.size, it.stride, st, &(*made)[i], spo, &pl, true);
+            if (rc == CHAIN_BREAK) {
+                SEI_TRY(flush());
+                rc = conv_rulebook_begin(m, it.sp, it.size, it.stride, st, &(*made)[i], spo, &pl, false);
+            }
+            SEI_TRY(rc);
             if (pl.pending) levels->push_back(pl);
         }
     }
@@ -570,7 +598,11 @@ static int prebuild_like_impl(sei_metadata_t *m, sei_metadata_t *like, bool forw
     // forward and backward passes that follow find everything built and synchronise nothing.
     std::vector<sei_rulebook_t *> made;
     std::vector<PendingLevel> levels;
-    int rc0 = begin_rulebooks(m, items, (hipStream_t)stream, &made, &levels);
+    auto flush = [&]() -> int {
+        if (!levels.empty() && sync_stream((hipStream_t)stream) != hipSuccess) SEI_FAIL("rulebook: hipStreamSynchronize failed");
+        return finish_levels(&levels);
+    };
+    int rc0 = begin_rulebooks(m, items, (hipStream_t)stream, &made, &levels, flush);
     if (!levels.empty() && sync_stream((hipStream_t)stream) != hipSuccess && !rc0) {
         set_error("rulebook: hipStreamSynchronize failed");
         rc0 = 1;
@@ -618,26 +650,38 @@ int sei_input_build_like(sei_metadata_t *m, const int32_t *coords_dev, int64_t n
     }
     std::vector<sei_rulebook_t *> made;
     std::vector<PendingLevel> levels;
+    int rc = 0;
+    bool input_done = false;
+    const bool input_pending = pi.pending;
+    // synchronises once and gives the host every count that is pending: the input level's, then the levels' in order
+    auto flush = [&]() -> int {
+        if (((input_pending && !input_done) || !levels.empty()) && sync_stream(st) != hipSuccess) {
+            set_error("InputLayer: hipStreamSynchronize failed");
+            rc = 1;
+        }
+        if (!input_done) {
+            input_done = true;
+            std::lock_guard<std::mutex> lk(m->mu);
+            if (rc) {
+                pool_free(pi.slot_of); pool_free(pi.flag); pool_free(pi.err_total); stage_put(pi.host);
+            } else {
+                rc = build_input_level_finish(m, &pi, st, n_rows);
+            }
+        }
+        const int rf = finish_levels(&levels);
+        if (!rc) rc = rf;
+        return rc;
+    };
     if (pi.pending) {
         const std::string keep = sei_last_error();
-        (void)begin_rulebooks(m, like_items(like), st, &made, &levels);   // failures: see above
-        set_error(keep);
+        (void)begin_rulebooks(m, like_items(like), st, &made, &levels, flush);   // failures: see above
+        if (!rc) set_error(keep);   // (an error a mid-chain flush met stays: rc carries it)
     }
-    int rc = 0;
-    if ((pi.pending || !levels.empty()) && sync_stream(st) != hipSuccess) {
-        set_error("InputLayer: hipStreamSynchronize failed");
-        rc = 1;
+    if (rc) {   // a mid-chain flush failed: everything begun has been finished / released by it
+        (void)finish_levels(&levels);
+        return rc;
     }
-    {
-        std::lock_guard<std::mutex> lk(m->mu);
-        if (rc) {
-            pool_free(pi.slot_of); pool_free(pi.flag); pool_free(pi.err_total); stage_put(pi.host);
-        } else {
-            rc = build_input_level_finish(m, &pi, st, n_rows);
-        }
-    }
-    const int rf = finish_levels(&levels);
-    return rc ? rc : rf;
+    return flush();
 }
 
 int sei_metadata_prebuild_like(sei_metadata_t *m, sei_metadata_t *like, sei_stream_t stream) {

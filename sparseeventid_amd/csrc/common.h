@@ -160,6 +160,8 @@ struct Level {
     int64_t n_ub = 0;
     int32_t *coords = nullptr;  // [n,4] device
     HashTable ht;
+    bool failed = false;        // its discovery failed after it was registered (hash table full, lost synchronisation): every
+                                // later lookup of the level or of the rulebook that created it reports that instead of using it
 };
 
 // ---------------------------------------------------------------- rulebook
@@ -282,6 +284,9 @@ struct PendingLevel {
 int build_strided_level_begin(sei_metadata *m, Level *lin, const int32_t size[3], const int32_t stride[3], sei_rulebook *rb,
                               hipStream_t st, PendingLevel *pl);
 int build_strided_level_finish(PendingLevel *pl);
+// instead of finish when the read-back cannot be trusted (the stream synchronisation failed): releases what finish would
+// and marks the level failed
+void build_strided_level_abort(PendingLevel *pl);
 int export_rules(const TiledRules &t, int64_t *start_host, int32_t *rin, int32_t *rout, hipStream_t st);
 // conv_fwd.hip / conv_wave.hip
 // How one convolution (forward, or dX with the plane counts swapped) runs: decided ONCE per call from the plane
@@ -295,7 +300,8 @@ struct ConvPlan {
     int col_group = 0;   // kind 1: width of the column groups whose columns are stored permuted (0 = natural layout)
     int blocks = 1;      // column blocks (kind 1: weights stored as [block][K][nIn][nOut/blocks])
     int nt = 0, cs = 0, slj = 0, maxs = 0, g = 0;   // kind 1, g == 2: two-offset rounds (conv_round_mfma_kernel), g == 3: with refilled A fragments
-    int nw = 4;          // kind 1: waves per workgroup (4 or 8)
+    int nw = 4;          // kind 1: waves per workgroup (4, 8 or 16)
+    int mo = 0;          // kind 1, g == 2, nw == 16: offsets a round may span (2: conv_round_mfma_kernel, 3 / 4: conv_mround_mfma_kernel)
     size_t lds_bytes = 0;
 };
 ConvPlan plan_conv(int nIn, int nOut, int K, int64_t n_dst);
@@ -310,6 +316,7 @@ enum { DW_KERNEL_AUTO = 0, DW_KERNEL_REG = 1, DW_KERNEL_RING = 2 };
 int forced_dw_kernel();
 int dw_ring_timeouts(int *out, bool reset);
 bool plan_wave(int nIn, int nOut, int K, int64_t n_dst, ConvPlan *p);
+bool conv_rounds_64(int nIn, int nOut, int K, int64_t n_dst);   // conv_fwd.hip: the 64 -> 64 layers that take the multi-offset rounds
 bool plan_band(int nIn, int nOut, int K, int64_t n_dst, ConvPlan *p);
 bool plan_cols(int nIn, int nOut, int K, int64_t n_dst, ConvPlan *p);
 // stats (optional, MFMA kernels only): per-(tile, part) column sums of the OUTPUT rows, [n_parts][2][nOut] doubles

@@ -30,7 +30,7 @@
 // The family measured below the workgroup-tile kernel on every level (profiles/r03_conv_band_*.log) and is no plan's
 // choice; its LDS hand-offs are polled with BOUNDED loops, and a poll that ran out would carry on with slots that have not
 // landed (counted in g_band_timeouts, results wrong).  It therefore exists only in experiment builds
-// (make EXTRA=-DSEI_EXPERIMENTS: tools/sweep_band.py, tests/test_gpu_kernels_agree.py); the shipped library holds the stubs
+// (make EXTRA=-DSEI_EXPERIMENTS: tools/sweep_band.py, tests/test_gpu_kernels_agree.py); the shipped library does not compile this file (Makefile) and holds stubs in conv_fwd.hip
 // at the end of this file.
 #ifdef SEI_EXPERIMENTS
 
@@ -729,22 +729,6 @@ extern "C" int sei_debug_band_timeouts(int32_t *out, int32_t reset) {
         int z = 0;
         if (hipMemcpyToSymbol(HIP_SYMBOL(sei::g_band_timeouts), &z, sizeof(int)) != hipSuccess) return 1;
     }
-    return 0;
-}
-
-#else  // !SEI_EXPERIMENTS: the shipped library
-
-namespace sei {
-bool plan_band(int, int, int, int64_t, ConvPlan *) { return false; }
-int conv_forward_band(const TiledRules &, const ConvPlan &, const float *, const float *, const float *, float *, int, int,
-                      const float *, double *, hipStream_t) {
-    SEI_FAIL("conv_forward_band: the row-band kernels exist only in experiment builds (make EXTRA=-DSEI_EXPERIMENTS)");
-}
-}  // namespace sei
-
-extern "C" int sei_debug_band_timeouts(int32_t *out, int32_t reset) {
-    (void)reset;
-    if (out) *out = 0;   // no polled hand-off in the shipped library
     return 0;
 }
 

@@ -35,16 +35,7 @@
 #endif
 
 
-#ifndef SEI_EXPERIMENTS
-// the shipped library holds no column-owner kernel: measured, not adopted
-namespace sei {
-bool plan_cols(int, int, int, int64_t, ConvPlan *) { return false; }
-int conv_forward_cols(const TiledRules &, const ConvPlan &, const float *, const float *, const float *, float *, int, int,
-                      const float *, double *, hipStream_t, const ConvEpilogue &) {
-    SEI_FAIL("conv_forward: the column-owner kernel exists only in experiment builds");
-}
-}  // namespace sei
-#else
+#ifdef SEI_EXPERIMENTS   // the shipped library does not compile this file (Makefile); its stubs are in conv_fwd.hip
 namespace sei {
 
 // Diagnostic builds only (make EXTRA="-DSEI_EXPERIMENTS -DSEI_STAMPS"; tools/cols_stamps.py): every wave adds the s_memtime

@@ -646,6 +646,326 @@ __global__ __launch_bounds__(64 * NW, (NJ > 0 ? 4 : occ8_for(NT, 1, 2, 1))) void
     TRACE_END;
 }
 
+// ------------------------------------------------------------------------------------------ multi-offset rounds  [r5]
+// The rounds above may span TWO offsets.  A sixteen-wave round on a 256-row tile then fills 0.65 at level 1 of the DUNE batch
+// (5.7 sub-chunks per tile and nonempty offset), 0.83 / 0.88 at levels 2 / 3; spanning up to FOUR offsets: 0.87 / 0.95 / 0.96
+// (tools/round_stats.py --tile 256).  What kept the rounds at two offsets was the write-back: the sub-chunks of offset b may
+// touch rows that those of offset a touch, so the groups of a round are added to the LDS tile in offset order, a barrier
+// between any two -- and a barrier per group costs more than the fill returns (profiles/r04_conv_round_ab.log).  Here the
+// barriers that order the groups are the PHASE barriers of the next round, which are there anyway:
+//   group 0 of round r is added at the end of the round (behind its last MFMA, as before);
+//   group g >= 1 moves to a second register set and is added behind barrier g-1 of round r+1, i.e. in that round's phase g-1.
+// With MO <= NP (offsets per round <= phases per round) the last group of round r lands in phase MO-2 <= NP-2 of round r+1,
+// one barrier before group 0 of round r+1 is added: every pair of groups of different offsets is barrier-separated and in
+// offset order, groups of one offset touch distinct rows -- bit-identical to the kernels above.  Per phase the slices of all
+// MO offsets are staged (MO x 2 buffers x 16 SLJ x COUT floats), the pieces dealt over all sixteen waves; the segment table
+// lives in a lane register (K + 1 <= 64) with a bit mask of the nonempty offsets, so that planning a round costs no LDS
+// round trips.  Refilled A fragments and the counted vmcnt schedule are those of conv_round_mfma_kernel<.., NJ > 0>.
+// Diagnostic build only (make EXTRA="-DSEI_EXPERIMENTS -DSEI_STAMPS"; tools/mround_stamps.py): EVERY wave adds the s_memtime
+// ticks it spends in each part of the kernel below to g_mstamps[wave][slot].  The product build compiles none of it.
+#ifdef SEI_STAMPS
+__device__ unsigned long long g_mstamps[16][16];
+#define MST_DECL unsigned long long mst_t = __builtin_amdgcn_s_memtime(), mst_acc[16] = {}
+#define MST(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long n_ = __builtin_amdgcn_s_memtime(); \
+                    __builtin_amdgcn_sched_barrier(0); mst_acc[i] += n_ - mst_t; mst_t = n_; } while (0)
+#define MST_ADD(i, v) mst_acc[i] += (v)
+#define MST_FLUSH do { if (lane == 0) { for (int i_ = 0; i_ < 16; i_++) atomicAdd(&g_mstamps[wave & 15][i_], mst_acc[i_]); } } while (0)
+#else
+#define MST_DECL
+#define MST(i)
+#define MST_ADD(i, v)
+#define MST_FLUSH
+#endif
+
+struct MRound {
+    int q0;          // first tile-relative sub-chunk
+    int m;           // offsets (groups) in the round, 0 beyond the end of the tile
+    uint32_t offs;   // byte j: offset of group j (j >= m: the last one)
+    uint32_t ends;   // byte j: end of group j relative to q0 (j >= m: the round's sub-chunk count)
+};
+
+template <int NT, int NW, int NJ, int SLJ, int MO>
+__global__ __launch_bounds__(64 * NW, 4) void conv_mround_mfma_kernel(
+    const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ Y,
+    const int32_t *__restrict__ tile_sub_start, const int32_t *__restrict__ tile_seg,
+    const int32_t *__restrict__ sub_src, const uint8_t *__restrict__ sub_dst, int64_t n_dst, int K, int CIN, int n_tiles,
+    const float *__restrict__ init, int ldy, int blocks, double *__restrict__ stats, ConvEpilogue ep) {
+    extern __shared__ float lds[];
+    constexpr int NP = NJ / SLJ;   // phases of a round
+    static_assert(NJ % SLJ == 0 && NP >= 2, "NP >= 3: the refilled-fragment schedule; NP == 2: two long phases per round");
+    static_assert(MO >= 2 && MO <= 4 && MO <= NP, "group g of a round is written back in phase g - 1 of the next one");
+    constexpr int TR = 16 * NW, SL = 16 * SLJ, COUT = NT * 16, PIECES = SL * COUT / 256;
+    static_assert((SL * COUT) % 256 == 0, "a slice is a whole number of 1-KiB LDS-DMA pieces");
+    const int vid = xcd_item(n_tiles * blocks);
+    if (vid >= n_tiles * blocks) return;
+    const int tile = vid / blocks, cblk = vid - tile * blocks;
+    W += (size_t)cblk * K * CIN * COUT;
+    if (bias) bias += cblk * COUT;
+    const int ycol0 = cblk * COUT;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r16 = lane & 15, g = lane >> 4;
+    float *acc_tile = lds;
+    float *wbuf = lds + (size_t)TR * COUT;   // [buffer][group][SL][COUT]
+    MST_DECL;
+
+    // segment table: lane i holds seg[i] (i <= K < 64); bit i of `nonempty`: offset i has sub-chunks in this tile
+    const int32_t *segp = tile_seg + (size_t)tile * (K + 1);
+    const int segv = segp[lane < K ? lane : K], segn = segp[lane + 1 < K ? lane + 1 : K];
+    const unsigned long long nonempty = __ballot(segn > segv);
+    auto seg_at = [&](int i) { return __builtin_amdgcn_readlane(segv, __builtin_amdgcn_readfirstlane(i)); };
+    auto next_nonempty = [&](int c) {   // smallest nonempty offset > c (K if none); c in [-1, K)
+        const unsigned long long m = nonempty >> (c + 1);
+        return m ? c + 1 + (int)__builtin_ctzll(m) : K;
+    };
+    tile_init<TR, COUT, 64 * NW>(acc_tile, bias, init, (int64_t)tile * TR, n_dst, ldy, ycol0);
+    __syncthreads();
+
+    const int64_t sub0 = tile_sub_start[tile];
+    const int n = seg_at(K);
+    auto cnt_of = [&](const MRound &r) { return (int)((r.ends >> (8 * (MO - 1))) & 0xFF); };
+    auto last_of = [&](const MRound &r) { return (int)((r.offs >> (8 * (MO - 1))) & 0xFF); };
+    auto plan = [&](int q0, int c) {   // the round starting at sub-chunk q0; c: an offset at or below the one holding q0
+        MRound r;
+        r.q0 = q0;
+        if (q0 >= n) { r.m = 0; r.offs = 0x01010101u * (uint32_t)(c < K ? c : K - 1); r.ends = 0; return r; }
+        while (seg_at(c + 1) <= q0) c = next_nonempty(c);
+        uint32_t offs = 0, ends = 0;
+        int m = 0, e = 0;
+        bool open = true;
+#pragma unroll
+        for (int j = 0; j < MO; j++) {
+            if (open) {
+                const int end = seg_at(c + 1) - q0;
+                e = end < NW ? end : NW;
+                m = j + 1;
+            }
+            offs |= (uint32_t)c << (8 * j);
+            ends |= (uint32_t)e << (8 * j);
+            if (open) {
+                if (e == NW) open = false;
+                else {
+                    const int c2 = next_nonempty(c);
+                    if (c2 >= K) open = false; else c = c2;
+                }
+            }
+        }
+        r.m = m; r.offs = offs; r.ends = ends;
+        return r;
+    };
+    struct Idx { int src; uint32_t d4; };
+    auto load_idx = [&](const MRound &r) {  // clamped: never branch around a load; validity is applied where it is used
+        const int q = r.q0 + wave, q1 = r.q0 + cnt_of(r);
+        const int qc = q < q1 ? q : (r.q0 < n ? r.q0 : n - 1);
+        const int64_t sb = (sub0 + qc) * SUB_SLOTS;
+        Idx v;
+        v.src = sub_src[sb + r16];
+        v.d4 = *reinterpret_cast<const uint32_t *>(sub_dst + sb + 4 * g);
+        return v;
+    };
+    auto stage = [&](const MRound &r, int s, int buf) {   // slice s of every offset of round r; pieces dealt over all waves
+#ifdef SEI_ABL_NODMA   // diagnostic: the weight slices are never staged (results wrong, timing only)
+        if (r.q0 >= 0) return;
+#endif
+        constexpr int TOT = MO * PIECES, PER = (TOT + NW - 1) / NW;
+        float *dst = wbuf + (size_t)buf * MO * SL * COUT;
+#pragma unroll
+        for (int t = 0; t < PER; t++) {
+            const int lin = wave + t * NW, j = lin / PIECES, p = lin - j * PIECES;   // wave-uniform
+            if (lin < TOT && j < r.m) {
+                const int off = (r.offs >> (8 * j)) & 0xFF;
+                const float *gp = W + ((size_t)off * CIN + (size_t)s * SL) * COUT + p * 256 + lane * 4;
+                float *lp = dst + (size_t)j * SL * COUT + p * 256;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gp,
+                                                 (__attribute__((address_space(3))) void *)lp, 16, 0, 0);
+            }
+        }
+        asm volatile("" ::: "memory");   // requested BEFORE the gathers that follow (the counted waits rely on it)
+    };
+
+    if (n > 0) {
+        MRound r0 = plan(0, 0), r1 = plan(cnt_of(r0), last_of(r0)), r2 = plan(r1.q0 + cnt_of(r1), last_of(r1));
+        Idx ic = load_idx(r0), i1 = load_idx(r1), i2 = load_idx(r2);
+        stage(r0, 0, 0);
+        float4 a_c[NP][1][SLJ];
+#pragma unroll
+        for (int j = 0; j < NP; j++)
+#pragma unroll
+            for (int jj = 0; jj < SLJ; jj++)
+                a_c[j][0][jj] = load_a(X, wave < cnt_of(r0) ? ic.src : -1, CIN, 16 * (SLJ * j + jj) + 4 * g);
+        int phase = 0;
+        f32x4 acc[1][NT], pacc[NT];
+        // tile rows += the partial sums `v` of a sub-chunk (d4: its packed dst rows, nv: rule slots in it)
+        // (two column tiles at a time: the deferred groups are added in the middle of the next round, when the fragments, both
+        // accumulator sets and the B operands are live -- 4 NT registers of tile values there meant spills from 128 planes on)
+        auto rmw = [&](const f32x4 (&v)[NT], uint32_t d4, int nv) {
+#ifdef SEI_ABL_NORMW   // diagnostic: the sums are not added into the LDS tile (results wrong, timing only)
+            if (d4 != 0xFFFFFFFFu) {
+#pragma unroll
+                for (int nn = 0; nn < NT; nn++) asm volatile("" ::"v"(v[nn]));
+                return;
+            }
+#endif
+            float *prow[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) prow[i] = acc_tile + ((d4 >> (8 * i)) & 0xFF) * COUT + r16;
+#pragma unroll
+            for (int n0 = 0; n0 < NT; n0 += 2) {
+                f32x4 tv[2];
+#pragma unroll
+                for (int nn = n0; nn < n0 + 2 && nn < NT; nn++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) tv[nn - n0][i] = prow[i][16 * nn];
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    if (4 * g + i < nv) {
+#pragma unroll
+                        for (int nn = n0; nn < n0 + 2 && nn < NT; nn++) prow[i][16 * nn] = tv[nn - n0][i] + v[nn][i];
+                    }
+            }
+        };
+        int pend_g = 0;        // group (>= 1) of the sub-chunk whose sums wait in pacc; 0: none
+        uint32_t pend_d4 = 0;
+        int pend_nv = 0;
+        MST(5);
+        while (r0.q0 < n) {
+            const int cnt0 = cnt_of(r0);
+            const bool valid = wave < cnt0;                    // wave-uniform
+            int gi = 0;                                        // the group (offset of the round) this wave's sub-chunk belongs to
+#pragma unroll
+            for (int j = 0; j + 1 < MO; j++) gi += wave >= (int)((r0.ends >> (8 * j)) & 0xFF) ? 1 : 0;
+            const int rowc = valid ? ic.src : -1, rown = (wave < cnt_of(r1)) ? i1.src : -1;
+            MRound r3 = r2;
+            Idx i3 = i2;
+            if constexpr (NP == 2) {
+                // [r5] TWO LONG PHASES per round (64 input planes: 2 x 32).  Ablation builds of the four-phase form at level 1
+                // (profiles/r05_mround_ablation_L1_C64.log) showed its phases -- 16 MFMAs per wave, ~2000 cycles of matrix work per
+                // SIMD -- to be as long as a weight slice takes to land: with the MFMAs removed the kernel keeps 63 % of its time,
+                // MFMA time and the rest ADD.  Here a phase holds 32 MFMAs per wave and every request has one such phase to land:
+                // the barrier's wait is a plain vmcnt(0) on loads issued ~4000 cycles earlier.
+                //   P0: [slices 32..63 of this round][fragments 32..63 of this round's sub-chunk][index words of round r + 3]
+                //   P1: [slices 0..31 of the next round][fragments 0..31 of the next round's sub-chunk]
+                // a_c[0] / a_c[1] are each refilled in the phase after their use (one register set).
+                static_for<2>([&](auto sc) {
+                    constexpr int s = decltype(sc)::value;
+                    MST(4);
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" SEI_BARRIER_INSN ::: "memory");
+                    MST(0);
+                    // everything requested so far has landed: tell hipcc, so that it plants no wait of its own behind the
+                    // requests of THIS phase
+#pragma unroll
+                    for (int jj = 0; jj < SLJ; jj++)
+                        asm volatile("" : "+v"(a_c[s][0][jj].x), "+v"(a_c[s][0][jj].y), "+v"(a_c[s][0][jj].z), "+v"(a_c[s][0][jj].w));
+                    asm volatile("" : "+v"(i3.src), "+v"(i3.d4));
+                    if (s == 0) stage(r0, 1, 1); else stage(r1, 0, 0);
+#pragma unroll
+                    for (int jj = 0; jj < SLJ; jj++)
+                        a_c[1 - s][0][jj] = load_a(X, s == 0 ? rowc : rown, CIN, 16 * (SLJ * (1 - s) + jj) + 4 * g);
+                    asm volatile("" ::: "memory");
+                    if (s == 0) {
+                        r3 = plan(r2.q0 + cnt_of(r2), last_of(r2));
+                        i3 = load_idx(r3);
+                        asm volatile("" ::: "memory");
+                        MST(1);
+                        if (pend_g == 1) {   // group 1 of the previous round, behind this barrier (MO == 2)
+                            rmw(pacc, pend_d4, pend_nv);
+                            pend_g = 0;
+                        }
+#pragma unroll
+                        for (int nn = 0; nn < NT; nn++) acc[0][nn] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        MST(2);
+                    } else {
+                        MST(1);
+                    }
+                    if (valid)
+                        compute_phase<NT, SLJ, 1, 1, COUT>(wbuf + (size_t)(s * MO + gi) * SL * COUT, a_c[s], acc, g, r16);
+                    MST(3);
+                    MST_ADD(8, valid ? 1 : 0);
+                    MST_ADD(9, valid ? 0 : 1);
+                });
+            } else {
+                constexpr int IDXP = NP >= 4 ? 2 : 1;   // the phase that requests the index words of round r + 3
+                // Queue of one phase: [slices of the next phase][SLJ gathers]([index loads x 2] in phase IDXP): see the kernel above
+                static_for<NP>([&](auto sc) {
+                    constexpr int s = decltype(sc)::value;
+                    MST(4);
+                    if (phase == 0)
+                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" SEI_BARRIER_INSN ::: "memory");
+                    else if (s == (IDXP + 1) % NP)
+                        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\t" SEI_BARRIER_INSN ::"n"(SLJ + 2) : "memory");
+                    else
+                        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\t" SEI_BARRIER_INSN ::"n"(SLJ) : "memory");
+                    MST(0);
+                    {
+                        constexpr int jg = (s + 3 * NP - 3) % NP;   // the gathers of two phases ago are in (no wait of hipcc's own)
+    #pragma unroll
+                        for (int jj = 0; jj < SLJ; jj++)
+                            asm volatile("" : "+v"(a_c[jg][0][jj].x), "+v"(a_c[jg][0][jj].y), "+v"(a_c[jg][0][jj].z), "+v"(a_c[jg][0][jj].w));
+                    }
+                    const bool same = s + 1 < NP;
+                    stage(same ? r0 : r1, same ? s + 1 : 0, (phase + 1) & 1);
+                    {
+                        constexpr int jr = (s + NP - 1) % NP;   // the fragments the previous phase used
+    #pragma unroll
+                        for (int jj = 0; jj < SLJ; jj++)
+                            a_c[jr][0][jj] = load_a(X, s == 0 ? rowc : rown, CIN, 16 * (SLJ * jr + jj) + 4 * g);
+                        asm volatile("" ::: "memory");
+                    }
+                    if (s == IDXP) {
+                        r3 = plan(r2.q0 + cnt_of(r2), last_of(r2));
+                        i3 = load_idx(r3);
+                        asm volatile("" ::: "memory");
+                    }
+                    MST(1);
+                    if constexpr (s + 1 < MO) {   // group s + 1 of the previous round: every earlier group is behind a barrier
+                        if (pend_g == s + 1) {
+                            rmw(pacc, pend_d4, pend_nv);
+                            pend_g = 0;
+                        }
+                    }
+                    if (s == 0) {
+    #pragma unroll
+                        for (int nn = 0; nn < NT; nn++) acc[0][nn] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                    MST(2);
+                    if (valid)
+                        compute_phase<NT, SLJ, 1, 1, COUT>(wbuf + (size_t)((phase & 1) * MO + gi) * SL * COUT, a_c[s], acc, g, r16);
+                    MST(3);
+                    MST_ADD(8, valid ? 1 : 0);
+                    MST_ADD(9, valid ? 0 : 1);
+                    phase++;
+                });
+            }
+            const int nv = __popcll(__ballot(rowc >= 0) & 0xFFFFull);
+            if (valid && gi == 0) rmw(acc[0], ic.d4, nv);
+            if (valid && gi > 0) {
+#pragma unroll
+                for (int nn = 0; nn < NT; nn++) pacc[nn] = acc[0][nn];
+                pend_g = gi;
+                pend_d4 = ic.d4;
+                pend_nv = nv;
+            }
+            r0 = r1; r1 = r2; r2 = r3;
+            ic = i1; i1 = i2; i2 = i3;
+            MST_ADD(10, 1);
+        }
+        MST(4);
+        // the last round's groups 1 .. MO-1, in order
+#pragma unroll
+        for (int gq = 1; gq < MO; gq++) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" SEI_BARRIER_INSN ::: "memory");
+            if (pend_g == gq) rmw(pacc, pend_d4, pend_nv);
+        }
+    }
+    __syncthreads();
+    MST(6);
+    const int64_t row0 = (int64_t)tile * TR;
+    tile_store<TR, COUT, 64 * NW>(acc_tile, Y, row0, n_dst, ldy, ycol0, ep);
+    if (stats) tile_stats<TR, COUT, 64 * NW>(acc_tile, stats, tile, row0, n_dst, ldy, ycol0);
+    MST(7);
+    MST_ADD(11, 1);
+    MST_FLUSH;
+}
+
 // Stem-type convolutions (tiny nIn, e.g. 1 -> 32 with 125 offsets): all of W sits in LDS, lane = output plane so that
 // every LDS accumulator access is a contiguous row segment.  HBM / LDS bound, no MFMA (64 flop per rule).
 // [r3] no barrier per offset any more: wave w OWNS rows [w TR/4, (w+1) TR/4) of the tile.  A 256-row tile holds ~19 rules
@@ -829,15 +1149,47 @@ static bool env_plan(int nOut, int *maxs, int *cs, int *slj, int *blocks, int *n
 }
 #endif
 
-// sixteen-wave instantiations of the round kernel: slice width / 16 (0: none) for NT column tiles and nIn input planes
-static int round16_slj(int nt, int nIn) {
-    if (nIn % 32 == 0 && nIn >= 96 && nIn <= 192) {
-        if (nt == 6 && (nIn == 96 || nIn == 128)) return 2;
-        if (nt == 4 && (nIn == 96 || nIn == 128 || nIn == 160 || nIn == 192)) return 2;
-        if (nt == 5 && (nIn == 128 || nIn == 160 || nIn == 192)) return 2;
+// sixteen-wave instantiations of the round kernels for NT column tiles and nIn input planes: slj = slice width / 16 (0: none),
+// mo = offsets a round may span (2: conv_round_mfma_kernel; 3 / 4: conv_mround_mfma_kernel, whose LDS holds mo slices per buffer)
+struct Round16 { int slj, mo, fam; };   // fam 2: conv_round_mfma_kernel, 3: conv_mround_mfma_kernel
+static Round16 round16_plan(int nt, int nIn) {
+    int mo_cap = 4;
+#ifdef SEI_EXPERIMENTS
+    if (const char *e = getenv("SEI_ROUND_MO")) mo_cap = atoi(e);
+    const char *l2 = getenv("SEI_ROUND_LONG");   // "0": the four-phase forms at 64 input planes
+    const bool long2 = !l2 || atoi(l2) != 0;
+#else
+    const bool long2 = true;
+#endif
+    // [r5] 64 input planes: two long phases of 32 planes per round, two offsets (conv_mround_mfma_kernel<NT, 16, 4, 2, 2>)
+    if (long2 && nIn == 64 && (nt == 4 || nt == 6)) return {2, 2, 3};
+    if (mo_cap >= 3 && nIn % 16 == 0) {
+        // [r5] multi-offset rounds: the widest slice and the most offsets whose buffers fit beside the 256-row tile
+        Round16 r{0, 0, 3};
+        if (nt == 4 && nIn == 64) r = {1, 4, 3};
+        if (nt == 4 && nIn == 96) r = {2, 3, 3};
+        if (nt == 4 && (nIn == 128 || nIn == 160 || nIn == 192)) r = {2, 4, 3};
+        if (nt == 5 && (nIn == 128 || nIn == 160 || nIn == 192)) r = {2, 3, 3};
+        if (nt == 6 && (nIn == 64 || nIn == 96 || nIn == 128)) r = {1, 4, 3};
+        if (r.mo > mo_cap) r.mo = mo_cap;
+        if (r.slj) return r;
     }
-    if (nt == 6 && nIn == 64) return 1;
-    return 0;
+    if (nIn % 32 == 0 && nIn >= 96 && nIn <= 192) {
+        if (nt == 6 && (nIn == 96 || nIn == 128)) return {2, 2, 2};
+        if (nt == 4 && (nIn == 96 || nIn == 128 || nIn == 160 || nIn == 192)) return {2, 2, 2};
+        if (nt == 5 && (nIn == 128 || nIn == 160 || nIn == 192)) return {2, 2, 2};
+    }
+    if (nt == 6 && nIn == 64) return {1, 2, 2};
+    return {0, 0, 0};
+}
+
+// [r5] the 64 -> 64 plane layers of large levels (level 1 of the DUNE network) leave the wave-private kernel for the
+// sixteen-wave multi-offset rounds (conv_mround_mfma_kernel<4, 16, 4, 1, 4>)
+bool conv_rounds_64(int nIn, int nOut, int K, int64_t n_dst) {
+#ifdef SEI_EXPERIMENTS
+    if (const char *e = getenv("SEI_L1_ROUNDS")) if (atoi(e) == 0) return false;   // A/B: the wave kernel keeps level 1
+#endif
+    return nIn == 64 && nOut == 64 && K + 1 <= 64 && n_dst >= 100000;
 }
 
 static ConvPlan plan_tile(int nIn, int nOut, int K, int64_t n_dst) {
@@ -872,7 +1224,7 @@ static ConvPlan plan_tile(int nIn, int nOut, int K, int64_t n_dst) {
         // builds interleaved twice on one box) -- they stay behind sei_debug_force_conv_kernel(5)
         if (nOut == 96 || ((nOut == 128 || nOut == 160) && (n_dst >= 100000 || kind_forced == CONV_KERNEL_ROUNDS)) ||
             (nOut == 192 && (n_dst >= 18000 || kind_forced == CONV_KERNEL_ROUNDS)) ||
-            (nOut == 64 && kind_forced == CONV_KERNEL_ROUNDS)) {
+            (nOut == 64 && (kind_forced == CONV_KERNEL_ROUNDS || (kind_forced == CONV_KERNEL_AUTO && conv_rounds_64(nIn, nOut, K, n_dst))))) {
             // 96 / 128 / 160 columns: eight-wave workgroups -- one sub-chunk per wave and offset on 128-row tiles, two
             // column blocks, 16-plane weight slices: 30-50 KB of LDS and 60-90 VGPRs (no spills), three or four
             // workgroups (24-32 waves) per CU.  A phase is one latency chain (barrier -> B from LDS -> MFMA -> LDS
@@ -903,11 +1255,12 @@ static ConvPlan plan_tile(int nIn, int nOut, int K, int64_t n_dst) {
                 // with 32-plane slices -- half the phases, half the weight staging per sub-chunk, padding 0.95 instead of 0.90:
                 // 88.1 / 92.9 / 89.0 against 84.7 / 86.4 / 86.6 TFLOP/s at 96 / 128 / 160 planes (profiles/r04_conv_round_ab.log)
                 const int cols = nOut / p.blocks;
-                bool wide = round16_slj(cols / 16, nIn) > 0;
+                const Round16 r16p = K + 1 <= 64 ? round16_plan(cols / 16, nIn) : Round16{0, 0, 0};
+                bool wide = r16p.slj > 0;
 #ifdef SEI_EXPERIMENTS
                 if (const char *e = getenv("SEI_ROUND_NW")) wide = wide && atoi(e) == 16;
 #endif
-                if (wide) { p.nw = 16; p.slj = 2 * round16_slj(cols / 16, nIn); }
+                if (wide) { p.nw = 16; p.mo = r16p.mo; p.g = r16p.fam; p.slj = r16p.mo * r16p.slj; }   // slj sizes the LDS: mo slices per buffer
             }
         }
 #ifdef SEI_EXPERIMENTS
@@ -938,6 +1291,21 @@ static ConvPlan plan_tile(int nIn, int nOut, int K, int64_t n_dst) {
     return p;
 }
 
+#ifndef SEI_EXPERIMENTS
+// The row-band / ring-tile (conv_band.hip) and column-owner (conv_cols.hip, 4.3f) families were measured and are
+// never a plan's choice: the shipped library does not compile those files (Makefile: SRCS) and holds these stubs instead.
+bool plan_band(int, int, int, int64_t, ConvPlan *) { return false; }
+bool plan_cols(int, int, int, int64_t, ConvPlan *) { return false; }
+int conv_forward_band(const TiledRules &, const ConvPlan &, const float *, const float *, const float *, float *, int, int,
+                      const float *, double *, hipStream_t) {
+    SEI_FAIL("conv_forward_band: the row-band kernels exist only in experiment builds (make EXTRA=-DSEI_EXPERIMENTS)");
+}
+int conv_forward_cols(const TiledRules &, const ConvPlan &, const float *, const float *, const float *, float *, int, int,
+                      const float *, double *, hipStream_t, const ConvEpilogue &) {
+    SEI_FAIL("conv_forward: the column-owner kernel exists only in experiment builds (make EXTRA=-DSEI_EXPERIMENTS)");
+}
+#endif
+
 // the plan of one convolution call (forward, or dX with the plane counts swapped)
 ConvPlan plan_conv(int nIn, int nOut, int K, int64_t n_dst) {
     ConvPlan p{};
@@ -963,6 +1331,26 @@ static int launch_round(const TiledRules &t, const ConvPlan &p, const float *X, 
                         int nIn, const float *init, double *stats, hipStream_t st, const ConvEpilogue &ep) {
     // one register set of A fragments refilled a phase after use (NJ = nIn / 16 > 0) where 128 registers hold it; the narrower
     // column blocks keep the per-phase gathers and three workgroups per CU
+    if (p.nw == 16 && p.g == 3) {   // [r5] sixteen-wave rounds spanning up to p.mo offsets / with two long phases (conv_mround_mfma_kernel)
+#define MROUND16(NJ_, SLJ_, MO_)                                                                                           \
+        if (nIn == 16 * NJ_ && p.mo == MO_ && p.slj == MO_ * SLJ_) {                                                       \
+            SEI_TRY(ensure_max_lds((const void *)conv_mround_mfma_kernel<NT, 16, NJ_, SLJ_, MO_>, 160 * 1024));            \
+            conv_mround_mfma_kernel<NT, 16, NJ_, SLJ_, MO_><<<((t.n_tiles * p.blocks + 7) / 8) * 8, 1024, p.lds_bytes, st>>>( \
+                X, W, bias, Y, t.tile_sub_start, t.tile_seg, t.sub_src, t.sub_dst, t.n_dst, t.K, nIn, t.n_tiles, init,     \
+                NT * 16 * p.blocks, p.blocks, stats, ep);                                                                  \
+            SEI_LAUNCH_CHECK();                                                                                            \
+            return 0;                                                                                                      \
+        }
+        if constexpr (NT == 4) { MROUND16(4, 2, 2) MROUND16(4, 1, 4) MROUND16(6, 2, 3) MROUND16(8, 2, 4) MROUND16(10, 2, 4) MROUND16(12, 2, 4) }
+        if constexpr (NT == 5) { MROUND16(8, 2, 3) MROUND16(10, 2, 3) MROUND16(12, 2, 3) }
+        if constexpr (NT == 6) { MROUND16(4, 2, 2) MROUND16(4, 1, 4) MROUND16(6, 1, 4) MROUND16(8, 1, 4) }
+#ifdef SEI_EXPERIMENTS   // SEI_ROUND_MO=3
+        if constexpr (NT == 4) { MROUND16(4, 1, 3) MROUND16(8, 2, 3) MROUND16(10, 2, 3) MROUND16(12, 2, 3) }
+        if constexpr (NT == 6) { MROUND16(4, 1, 3) MROUND16(6, 1, 3) MROUND16(8, 1, 3) }
+#endif
+#undef MROUND16
+        SEI_FAIL("conv_forward: no multi-offset round instantiation for this plan");
+    }
     if (p.nw == 16) {   // one sixteen-wave workgroup per CU, refilled fragments, 32-plane slices (16-plane behind 64 planes)
 #define ROUND16(NJ_, SLJ_)                                                                                               \
         if (nIn == 16 * NJ_ && p.slj == 2 * SLJ_) {                                                                      \
@@ -1081,7 +1469,7 @@ int conv_forward(const TiledRules &t, const float *X, const float *W, const floa
     if (p.kind == 2) return conv_forward_wave(t, p, X, W, bias, Y, nIn, nOut, init, stats, st, epv);
     if (p.kind == 3) return conv_forward_band(t, p, X, W, bias, Y, nIn, nOut, init, stats, st);
     if (p.kind == 4) return conv_forward_cols(t, p, X, W, bias, Y, nIn, nOut, init, stats, st, epv);
-    if (p.kind == 1 && p.g == 2) {
+    if (p.kind == 1 && (p.g == 2 || p.g == 3)) {
         if (nIn % 16 || nIn < 64) SEI_FAIL("conv_forward: the round kernel needs nIn % 16 == 0 and nIn >= 64");
 #define ROUND_CASE(NT_) if (p.nt == NT_) return launch_round<NT_>(t, p, X, W, bias, Y, nIn, init, stats, st, epv);
         ROUND_CASE(3) ROUND_CASE(4) ROUND_CASE(5) ROUND_CASE(6)
@@ -1137,6 +1525,14 @@ int conv_forward(const TiledRules &t, const float *X, const float *W, const floa
 
 }  // namespace sei
 
+#ifndef SEI_EXPERIMENTS
+extern "C" int sei_debug_band_timeouts(int32_t *out, int32_t reset) {
+    (void)reset;
+    if (out) *out = 0;   // no polled hand-off in the shipped library
+    return 0;
+}
+#endif
+
 #ifdef SEI_TRACE
 extern "C" int sei_debug_trace(void *out, long long bytes, int reset) {
     if (out && bytes > 0) {
@@ -1154,6 +1550,14 @@ extern "C" long long sei_debug_trace_bytes(void) { return (long long)sizeof(sei:
 #endif
 
 #ifdef SEI_STAMPS
+extern "C" int sei_debug_mround_stamps(unsigned long long *out, int reset) {   // [16 waves][16 slots]
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(sei::g_mstamps), sizeof(sei::g_mstamps)) != hipSuccess) return 1;
+    if (reset) {
+        static unsigned long long z[16][16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(sei::g_mstamps), z, sizeof(z)) != hipSuccess) return 1;
+    }
+    return 0;
+}
 extern "C" int sei_debug_stamps(unsigned long long *out, int reset) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(sei::g_stamps), sizeof(sei::g_stamps)) != hipSuccess) return 1;
     if (reset) {

@@ -399,6 +399,7 @@ bool plan_wave(int nIn, int nOut, int K, int64_t n_dst, ConvPlan *p) {
     if (env) { nt = en; tr = et; g = eg; }
 #endif
     if (!forced && !env && nOut != 32 && nOut != 64) return false;
+    if (!forced && !env && conv_rounds_64(nIn, nOut, K, n_dst)) return false;   // [r5] sixteen-wave multi-offset rounds (conv_fwd.hip)
     if ((size_t)tr * nt * 16 * sizeof(float) > 64 * 1024) return false;
     p->kind = 2; p->tile_rows = tr; p->col_group = 0; p->blocks = tiles / nt; p->nt = nt; p->g = g;
     p->lds_bytes = (size_t)tr * nt * 16 * sizeof(float);

@@ -509,6 +509,7 @@ Level *find_level(sei_metadata *m, const int32_t spatial[3]) {
     return nullptr;
 }
 
+
 // Discovers the output active set of a strided convolution and registers it as a new level -- in two halves around the ONE
 // device -> host read-back of the site count:
 //   begin : tables and arrays sized for an UPPER BOUND of the input rows (every input row yields at most `mult` candidates),
@@ -612,15 +613,33 @@ int build_strided_level_finish(PendingLevel *pl) {
     pool_free(pl->total);
     stage_put(pl->host);
     pl->total = nullptr; pl->host = nullptr; pl->pending = false;
-    if (full) SEI_FAIL("Convolution: hash table full");
+    if (full) {
+        lo->failed = true;   // the level and its rulebook are registered already: lookups must not hand them out (round-4 advisor)
+        lo->n = 0;
+        SEI_FAIL("Convolution: hash table full");
+    }
     return 0;
+}
+
+void build_strided_level_abort(PendingLevel *pl) {
+    if (!pl->pending) return;
+    Level *lo = pl->level;
+    lo->failed = true;
+    lo->n = 0;
+    lo->n_dev = nullptr;
+    pool_free(pl->total);
+    stage_put(pl->host);
+    pl->total = nullptr; pl->host = nullptr; pl->pending = false;
 }
 
 int build_strided_level(sei_metadata *m, Level *lin, const int32_t size[3], const int32_t stride[3], sei_rulebook *rb,
                         hipStream_t st) {
     PendingLevel pl;
     SEI_TRY(build_strided_level_begin(m, lin, size, stride, rb, st, &pl));
-    if (pl.pending && sync_stream(st) != hipSuccess) SEI_FAIL("rulebook: hipStreamSynchronize failed");
+    if (pl.pending && sync_stream(st) != hipSuccess) {
+        build_strided_level_abort(&pl);
+        SEI_FAIL("rulebook: hipStreamSynchronize failed");
+    }
     return build_strided_level_finish(&pl);
 }
 

@@ -666,6 +666,12 @@ class InputLayer(nn.Module):
         # InputLayer and all levels instead of one each).  None: the plain InputLayer.
         self.template = None
 
+    def __getstate__(self):
+        # the template is a live ctypes handle (device hash tables, rulebooks): never pickled or deep-copied with the model
+        state = self.__dict__.copy()
+        state["template"] = None
+        return state
+
     def forward(self, input):
         if isinstance(input, SparseConvNetTensor):
             # already an input-level tensor (built ahead of time, e.g. Trainer.prefetch on a side stream)

@@ -148,7 +148,10 @@ class Trainer:
         with torch.cuda.stream(self._side):
             layer = self.encoder.input_tensor if self.model == "sbnd" else self.encoder.input_layer
             layer.template = self._template if self.batch_rulebooks else None   # input level + strided levels: one read-back
-            t = layer(image)
+            try:
+                t = layer(image)
+            finally:
+                layer.template = None   # the layer must not keep a batch's metadata alive, nor carry it into a deepcopy / pickle
             for x in inputs:
                 x.record_stream(self._side)   # read by the side stream's kernels: not reusable before they are done
             try:
@@ -173,7 +176,10 @@ class Trainer:
             # with the previous batch's metadata as the template the InputLayer discovers the strided levels together with
             # the input level (scn.InputLayer.template -> sei_input_build_like: ONE count read-back for all of them)
             layer.template = self._template if self.batch_rulebooks else None
-            image = layer(image)     # Encoder.forward / ResNet.forward pass a prepared tensor through
+            try:
+                image = layer(image)     # Encoder.forward / ResNet.forward pass a prepared tensor through
+            finally:
+                layer.template = None
             if self.batch_rulebooks and self._template is not None and image.features.is_cuda:
                 # every rulebook (forward AND backward variants) the previous batch needed, built now with ONE count
                 # read-back for all of them instead of one per variant spread over the forward and backward passes;

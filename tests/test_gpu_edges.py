@@ -107,10 +107,12 @@ def test_125_offset_filter_on_the_mfma_path():
     assert rel_err(conv.weight.grad, W.grad) < 1e-4 and rel_err(f.grad, fo.grad) < 1e-4
 
 
-@pytest.mark.parametrize("ci,co", [(128, 128), (160, 160), (96, 192)])
+@pytest.mark.parametrize("ci,co", [(128, 128), (160, 160), (96, 192), (192, 192), (64, 64), (96, 96)])
 def test_wide_layers_on_a_large_level(ci, co):
     """>= 100 000 dst rows switch the wide layers (nOut > 96) to 128-row tiles with one workgroup per
-    (tile, column block): forward, dX (roles of ci / co swapped) and dW against the oracle."""
+    (tile, column block) -- since rounds 4 / 5 to the sixteen-wave round kernels on 256-row tiles, and the 64 -> 64 layers
+    leave the wave kernel for them: forward, dX (roles of ci / co swapped) and dW against the oracle, so that every
+    default instantiation of the round kernels (64 / 96 / 128 / 160 / 192 planes) meets the oracle directly."""
     import sparseeventid_amd.scn as scn
     from tests.util import random_cloud
     sp, B = [56, 56, 56], 2

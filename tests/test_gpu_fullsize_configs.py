@@ -113,14 +113,72 @@ def test_sbnd_network_full_size_step_is_finite_and_deterministic(sbnd_batch):
         assert torch.equal(g, g2[k]), k
 
 
-def test_dune3d_default_net_forward_only_32_events():
+@pytest.fixture(scope="module")
+def dune_batch64():
+    """bench.py's headline batch (rank 0, batch 0: seeds 0..63); its first 32 events are the 32-event batch of configs[1]"""
+    from bench import generate_batch
+    return generate_batch(0, 0, 64, (900, 900, 900), 50000, "tracks", 1)   # no fork: the GPU may be initialised
+
+
+def test_dune3d_default_net_training_step_64_events(dune_batch64):
+    """configs[2] AS A WHOLE (/root/reference/src/networks/resnet.py:141-161 under src/utils/create_trainer.py:50-58's
+    training loop): the default DUNE-3D network, 64 full-size events from bench.generate_batch, two `train_step`s (the second
+    one builds its rulebooks from the first one's template) -- finite loss and logits, every parameter receives a finite
+    gradient, a rerun from the same state is bit-identical, and the overlapped default of bench.py (dW on a side stream
+    joined once per backward pass, the next step's rulebooks built beside the running one) equals the serial step bit for
+    bit.  The oracle needs minutes at this size: it checks this network on 2 events (test_gpu_fullnet.py)."""
+    import gc
+    import sparseeventid_amd.scn as scn
+    from sparseeventid_amd.train import Trainer
+    arr, labels = dune_batch64
+    runs = {}
+    for name in ("serial", "serial again", "overlapped"):
+        tr = Trainer(image_size=[1, 900, 900, 900], device="cuda", seed=0)
+        image, lab = tr.stage(tr.to_scn_input(arr), labels)
+        ready = torch.cuda.Event()
+        ready.record()
+        over = name == "overlapped"
+        scn.set_backward_streams(2 if over else 0)
+        try:
+            loss1, logits1 = tr.train_step(tr.prefetch(image, after=ready) if over else image, lab)
+            grad1 = tr.arena.grad.clone()
+            nxt = tr.prefetch(image, after=ready) if over else image
+            loss2, _ = tr.train_step(nxt, lab)
+            torch.cuda.synchronize()
+        finally:
+            scn.set_backward_streams(0)
+        assert bool(torch.isfinite(loss1)) and bool(torch.isfinite(loss2)) and float(loss1) > 0
+        for k, v in logits1.items():
+            assert v.shape[0] == 64 and bool(torch.isfinite(v).all()), k
+        names = [n for m in (tr.encoder, tr.head) for n, _ in m.named_parameters()]
+        assert len(names) == len(tr.arena.spans)
+        for pname, (off, n) in zip(names, tr.arena.spans):
+            gp = grad1[off:off + n]
+            assert bool(torch.isfinite(gp).all()), pname
+            # (a bias in front of a BatchNorm has a mathematically zero gradient: rounding noise, possibly exact zeros)
+            if not pname.endswith("conv1.bias"):
+                assert float(gp.abs().max()) > 0, pname
+        runs[name] = (loss1.clone(), loss2.clone(), grad1, tr.arena.flat.clone(), {k: v.detach().clone() for k, v in logits1.items()})
+        del tr, image, lab, nxt, logits1
+        gc.collect()
+        torch.cuda.empty_cache()
+    ref = runs["serial"]
+    for name in ("serial again", "overlapped"):
+        got = runs[name]
+        assert torch.equal(ref[0], got[0]) and torch.equal(ref[1], got[1]), name      # losses of both steps
+        assert torch.equal(ref[2], got[2]), name                                      # every gradient of step 1
+        assert torch.equal(ref[3], got[3]), name                                      # parameters after two Adam steps
+        for k in ref[4]:
+            assert torch.equal(ref[4][k], got[4][k]), (name, k)
+
+
+def test_dune3d_default_net_forward_only_32_events(dune_batch64):
     """configs[1]: the default DUNE-3D network, eval-free forward (train-mode BatchNorm as bin/exec.py's iotest/forward
     path runs it under no_grad) on 32 full-size events: dense output shape, finite logits, tanh range, inactive cells
     exact zeros, bit-identical rerun, and the fused sparse head equals the dense head."""
-    from bench import generate_batch
     from sparseeventid_amd.train import Trainer
     grid = (900, 900, 900)
-    arr, labels = generate_batch(0, 0, 32, grid, 50000, "tracks", 1)
+    arr, labels = dune_batch64[0][:32], {k: v[:32] for k, v in dune_batch64[1].items()}
     tr = Trainer(image_size=[1] + list(grid), device="cuda", seed=0)
     image, _ = tr.stage(tr.to_scn_input(arr), labels)
     with torch.no_grad():

@@ -127,11 +127,12 @@ CONV_CASES = [(1, 32, [5, 5, 5]), (32, 32, [3, 3, 3]), (64, 64, [3, 3, 3]), (96,
               (256, 208, [1, 3, 3])]
 
 
-@pytest.mark.parametrize("kernel", ["default", "tile", "wave", "band"])
+@pytest.mark.parametrize("kernel", ["default", "tile", "wave", "band", "rounds"])
 @pytest.mark.parametrize("ci,co,filt", CONV_CASES)
 def test_subm_conv_forward_backward(ci, co, filt, kernel, force_conv_kernel):
-    """`kernel` forces the workgroup-tile, the wave-private or the row-band MFMA kernel (sei_debug_force_conv_kernel)
-    so that all three stay covered for every plane count whatever the default plan picks."""
+    """`kernel` forces the workgroup-tile, the wave-private or the row-band MFMA kernel, or the tile kernel's round forms
+    (two-offset and multi-offset rounds, wherever instantiated: sei_debug_force_conv_kernel) so that every family meets the
+    oracle DIRECTLY for every plane count, whatever the default plan picks."""
     if kernel != "default":
         if ci % 16 or co % 16:
             pytest.skip("scalar kernels: no MFMA variant to force")
@@ -159,7 +160,7 @@ def test_subm_conv_forward_backward(ci, co, filt, kernel, force_conv_kernel):
     assert rel_err(f.grad, fo.grad) < TOL
 
 
-@pytest.mark.parametrize("kernel", ["default", "tile", "wave", "band"])
+@pytest.mark.parametrize("kernel", ["default", "tile", "wave", "band", "rounds"])
 @pytest.mark.parametrize("ci,co,size", [(32, 64, [2, 2, 2]), (64, 96, [2, 2, 2]), (160, 192, [2, 2, 2]),
                                         (16, 32, [1, 2, 2]), (5, 7, [2, 2, 2]), (32, 32, [3, 3, 3])])
 def test_strided_conv_forward_backward(ci, co, size, kernel, force_conv_kernel):

@@ -466,3 +466,61 @@ def test_input_layer_with_a_template_discovers_the_levels_in_one_readback():
     # and an empty batch goes through
     e = tl((torch.zeros(0, 4), torch.zeros(0, 2).cuda(), 2))
     assert e.features.shape[0] == 0
+
+
+def test_overlapping_strided_filters_do_not_compound_their_bounds_along_a_chain():
+    """scn.Convolution(3, .., 3, 2) -- an OVERLAPPING filter: an input site may open up to 8 output sites -- chained four
+    levels deep through the template paths (sei_input_build_like, sei_metadata_prebuild_like).  A level begun behind an
+    unfinished one is sized by that one's UPPER bound; with 8 candidates per row the bound would compound 8x per level
+    (round-4 advisor: multi-GB tables, then 'too many candidate output sites').  The chain is broken there instead: one
+    synchronisation, exact sizes -- same levels, coordinates and rules as the lazy path, and a pool that stays small."""
+    import ctypes
+    import sparseeventid_amd.scn as scn
+    from sparseeventid_amd._lib import lib
+    sp = [95, 87, 91]   # (s - 3) // 2 + 1: 47/43/45 -> 23/21/22 -> 11/10/10 -> 5/4/4
+
+    def net(t):
+        out = []
+        f = torch.ones(t.features.shape[0], 16, device="cuda")
+        t = scn.SparseConvNetTensor(f, t.metadata, t.spatial_size)
+        for _ in range(4):
+            s3 = [int(v) for v in t.spatial_size]
+            conv = scn.Convolution(3, 16, 16, 3, 2, False).cuda()
+            with torch.no_grad():
+                conv.weight.fill_(1.0)
+                t = conv(t)
+            s3o = [int(v) for v in t.spatial_size]
+            out.append((t.features.shape[0], t.metadata.coords(s3o, "cuda").cpu().clone(), t.features.sum(1).cpu().clone()))
+        return out
+
+    def held():
+        h, u = ctypes.c_int64(), ctypes.c_int64()
+        lib().sei_pool_stats(ctypes.byref(h), ctypes.byref(u))
+        return h.value
+
+    layer = scn.InputLayer(3, sp)
+    ca, fa = blob_cloud(13, 2, sp, 20000, 1)
+    ta = layer((torch.from_numpy(ca), torch.from_numpy(fa).cuda(), 2))
+    want_a = net(ta)                                             # the template (lazy path: exact sizes)
+    cb, fb = blob_cloud(14, 2, sp, 18000, 1)
+    plain = layer((torch.from_numpy(cb), torch.from_numpy(fb).cuda(), 2))
+    want = net(plain)
+    torch.cuda.synchronize()
+    base = held()
+    tl = scn.InputLayer(3, sp)
+    tl.template = ta.metadata
+    fast = tl((torch.from_numpy(cb), torch.from_numpy(fb).cuda(), 2))      # sei_input_build_like: input level + chain
+    fast.metadata.prebuild_like(ta.metadata)                               # sei_metadata_prebuild_like: nothing left to discover
+    torch.cuda.synchronize()
+    # 18 000 points x 8 x 8 x 8 x 8 candidates would be 74 M x ~30 B = 2 GB of tables; exact sizing needs a few MB
+    assert held() - base < 256 << 20, (held() - base) / 1e6
+    got = net(fast)
+    for a, b in zip(want, got):
+        assert a[0] == b[0] and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    # and through prebuild_like alone (input level built the plain way, levels discovered by the prebuild)
+    plain2 = layer((torch.from_numpy(cb), torch.from_numpy(fb).cuda(), 2))
+    plain2.metadata.prebuild_like(ta.metadata)
+    got2 = net(plain2)
+    for a, b in zip(want, got2):
+        assert a[0] == b[0] and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert want_a[0][0] != want[0][0]                                      # the two batches differ
