@@ -297,18 +297,39 @@ def main():
     dt = time.perf_counter() - t0
     lib.sei_prof_enable(0)
     pool_end = pool_held_now()
-    single = None
+    def conv_tflop_per_step():
+        q = (ctypes.c_double * 4)()
+        tot = 0.0
+        for kind in (0, 1, 2, 6, 7):
+            lib.sei_prof_query(kind, q)
+            tot += q[2]
+        return tot / args.steps / 1e12
+
+    single = single_tflop = saved = None
+    cycled_tflop = conv_tflop_per_step() if not args.no_prof else None
     if nb > 1:
-        # the same loop on ONE batch (what rounds 1-4 reported as `value`): identical sizes every step
+        # the same loop on ONE batch (what rounds 1-4 reported as `value`): identical sizes every step.  The profile of the
+        # cycled loop (what `roofline` reports) is saved and restored around it; this loop's own flop count says how much
+        # of the difference between the two rates is the batches' different amounts of work.
+        if not args.no_prof:
+            saved = [(ctypes.c_double * 4)() for _ in range(8)]
+            for kind in range(8):
+                lib.sei_prof_query(kind, saved[kind])
         cur["cycle"] = False
         staged[0] = tr.prefetch(images[0], after=inputs_ready) if prefetch else images[0]
         step()
         fence()
+        if not args.no_prof:
+            lib.sei_prof_reset()
+            lib.sei_prof_enable(1)
         t1 = time.perf_counter()
         for _ in range(args.steps):
             step()
         fence()
         single = (time.perf_counter() - t1) / args.steps * 1e3
+        lib.sei_prof_enable(0)
+        if not args.no_prof:
+            single_tflop = conv_tflop_per_step()
     ms = dt / args.steps * 1e3
     sync = None
     if grouped:
@@ -382,7 +403,10 @@ def main():
             kinds = {}
             for kind, name in ((0, "conv_fwd"), (1, "conv_bwd_input"), (2, "conv_bwd_weight"), (3, "rulebook_build"),
                                (4, "batchnorm"), (6, "conv_fwd_32planes"), (7, "conv_bwd_input_32planes")):
-                lib.sei_prof_query(kind, q)
+                if saved is not None:      # the profile of the CYCLED loop (the single-batch loop ran after it)
+                    q = saved[kind]
+                else:
+                    lib.sei_prof_query(kind, q)
                 kinds[name] = {"launches": q[0], "ms": q[1], "gflop": q[2] / 1e9, "gbyte": q[3] / 1e9}
                 if kind in ((0, 6) if shared else (0, 1, 6, 7)):
                     tot_n += q[0]; tot_ms += q[1]; tot_fl += q[2]
@@ -478,7 +502,12 @@ def main():
         out["batches"] = {
             "distinct_batches_cycled": nb, "seeds": "1000003*rank + 64*b + e, b = 0..%d" % (nb - 1),
             # the same K steps on batch 0 alone (identical sizes every step: the quantity rounds 1-4 reported)
-            "single_batch_repeat": None if single is None else {"ms_per_step": single, "events_per_s": args.batch * world / (single * 1e-3)},
+            "single_batch_repeat": None if single is None else {
+                "ms_per_step": single, "events_per_s": args.batch * world / (single * 1e-3),
+                # what explains the difference: the batches hold different amounts of work (rules x planes)
+                "conv_tflop_per_step": single_tflop, "conv_tflop_per_step_cycled": cycled_tflop,
+                "ms_per_conv_tflop": None if not single_tflop else single / single_tflop,
+                "ms_per_conv_tflop_cycled": None if not cycled_tflop else ms / cycled_tflop},
             # bytes the library's device pool holds after the warm-up steps and after the timed loop: a pool that still
             # grows while the batches repeat would show here (warm-up must have seen every batch: warmup >= batches)
             "library_pool_held_after_warmup": pool_warm, "library_pool_held_after_timed_loop": pool_end,

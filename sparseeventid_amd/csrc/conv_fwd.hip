@@ -684,7 +684,10 @@ struct MRound {
     uint32_t ends;   // byte j: end of group j relative to q0 (j >= m: the round's sub-chunk count)
 };
 
-template <int NT, int NW, int NJ, int SLJ, int MO>
+// NB: weight buffers (NP >= 3 only).  2: the slices of phase p + 1 are staged in phase p and have ONE phase to land; 3: those of
+// phase p + 2, TWO phases (the third buffer is the LDS the 128 / 160 / 192-column plans leave unused; every wave then issues the
+// same number of pieces per phase -- surplus ones repeat a neighbour's -- so that the counted vmcnt waits stay exact).
+template <int NT, int NW, int NJ, int SLJ, int MO, int NB = 2>
 __global__ __launch_bounds__(64 * NW, 4) void conv_mround_mfma_kernel(
     const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ Y,
     const int32_t *__restrict__ tile_sub_start, const int32_t *__restrict__ tile_seg,
@@ -694,8 +697,10 @@ __global__ __launch_bounds__(64 * NW, 4) void conv_mround_mfma_kernel(
     constexpr int NP = NJ / SLJ;   // phases of a round
     static_assert(NJ % SLJ == 0 && NP >= 2, "NP >= 3: the refilled-fragment schedule; NP == 2: two long phases per round");
     static_assert(MO >= 2 && MO <= 4 && MO <= NP, "group g of a round is written back in phase g - 1 of the next one");
+    static_assert(NB == 2 || (NB == 3 && NP >= 3), "the third weight buffer belongs to the refilled-fragment schedule");
     constexpr int TR = 16 * NW, SL = 16 * SLJ, COUT = NT * 16, PIECES = SL * COUT / 256;
     static_assert((SL * COUT) % 256 == 0, "a slice is a whole number of 1-KiB LDS-DMA pieces");
+    constexpr int STAGE_PER = (MO * PIECES + NW - 1) / NW;   // pieces a wave issues per staged phase (NB == 3: exactly)
     const int vid = xcd_item(n_tiles * blocks);
     if (vid >= n_tiles * blocks) return;
     const int tile = vid / blocks, cblk = vid - tile * blocks;
@@ -766,12 +771,14 @@ __global__ __launch_bounds__(64 * NW, 4) void conv_mround_mfma_kernel(
 #ifdef SEI_ABL_NODMA   // diagnostic: the weight slices are never staged (results wrong, timing only)
         if (r.q0 >= 0) return;
 #endif
-        constexpr int TOT = MO * PIECES, PER = (TOT + NW - 1) / NW;
+        constexpr int TOT = MO * PIECES, PER = STAGE_PER;
         float *dst = wbuf + (size_t)buf * MO * SL * COUT;
 #pragma unroll
         for (int t = 0; t < PER; t++) {
-            const int lin = wave + t * NW, j = lin / PIECES, p = lin - j * PIECES;   // wave-uniform
-            if (lin < TOT && j < r.m) {
+            int lin = wave + t * NW;                                                  // wave-uniform
+            if (NB == 3 && lin >= TOT) lin -= NW;                                     // surplus piece: the previous one again
+            const int j = lin / PIECES, p = lin - j * PIECES;
+            if (NB == 3 || (lin < TOT && j < r.m)) {                                  // NB == 3: always (byte j >= m repeats the last offset)
                 const int off = (r.offs >> (8 * j)) & 0xFF;
                 const float *gp = W + ((size_t)off * CIN + (size_t)s * SL) * COUT + p * 256 + lane * 4;
                 float *lp = dst + (size_t)j * SL * COUT + p * 256;
@@ -786,6 +793,7 @@ __global__ __launch_bounds__(64 * NW, 4) void conv_mround_mfma_kernel(
         MRound r0 = plan(0, 0), r1 = plan(cnt_of(r0), last_of(r0)), r2 = plan(r1.q0 + cnt_of(r1), last_of(r1));
         Idx ic = load_idx(r0), i1 = load_idx(r1), i2 = load_idx(r2);
         stage(r0, 0, 0);
+        if (NB == 3) stage(r0, 1, 1);
         float4 a_c[NP][1][SLJ];
 #pragma unroll
         for (int j = 0; j < NP; j++)
@@ -793,6 +801,7 @@ __global__ __launch_bounds__(64 * NW, 4) void conv_mround_mfma_kernel(
             for (int jj = 0; jj < SLJ; jj++)
                 a_c[j][0][jj] = load_a(X, wave < cnt_of(r0) ? ic.src : -1, CIN, 16 * (SLJ * j + jj) + 4 * g);
         int phase = 0;
+        int bcur = 0;   // buffer the current phase reads (NB == 3: phase % 3)
         f32x4 acc[1][NT], pacc[NT];
         // tile rows += the partial sums `v` of a sub-chunk (d4: its packed dst rows, nv: rule slots in it)
         // (two column tiles at a time: the deferred groups are added in the middle of the next round, when the fragments, both
@@ -867,7 +876,7 @@ __global__ __launch_bounds__(64 * NW, 4) void conv_mround_mfma_kernel(
                         asm volatile("" ::: "memory");
                         MST(1);
                         if (pend_g == 1) {   // group 1 of the previous round, behind this barrier (MO == 2)
-                            rmw(pacc, pend_d4, pend_nv);
+                            rmw(MO == 2 ? acc[0] : pacc, pend_d4, pend_nv);
                             pend_g = 0;
                         }
 #pragma unroll
@@ -888,12 +897,14 @@ __global__ __launch_bounds__(64 * NW, 4) void conv_mround_mfma_kernel(
                 static_for<NP>([&](auto sc) {
                     constexpr int s = decltype(sc)::value;
                     MST(4);
+                    // NB == 3: the previous phase's pieces (for the NEXT phase) stay in flight as well
+                    constexpr int KEEP = SLJ + (NB == 3 ? STAGE_PER : 0);
                     if (phase == 0)
                         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" SEI_BARRIER_INSN ::: "memory");
                     else if (s == (IDXP + 1) % NP)
-                        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\t" SEI_BARRIER_INSN ::"n"(SLJ + 2) : "memory");
+                        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\t" SEI_BARRIER_INSN ::"n"(KEEP + 2) : "memory");
                     else
-                        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\t" SEI_BARRIER_INSN ::"n"(SLJ) : "memory");
+                        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\t" SEI_BARRIER_INSN ::"n"(KEEP) : "memory");
                     MST(0);
                     {
                         constexpr int jg = (s + 3 * NP - 3) % NP;   // the gathers of two phases ago are in (no wait of hipcc's own)
@@ -901,8 +912,13 @@ __global__ __launch_bounds__(64 * NW, 4) void conv_mround_mfma_kernel(
                         for (int jj = 0; jj < SLJ; jj++)
                             asm volatile("" : "+v"(a_c[jg][0][jj].x), "+v"(a_c[jg][0][jj].y), "+v"(a_c[jg][0][jj].z), "+v"(a_c[jg][0][jj].w));
                     }
-                    const bool same = s + 1 < NP;
-                    stage(same ? r0 : r1, same ? s + 1 : 0, (phase + 1) & 1);
+                    if (NB == 3) {
+                        const bool same2 = s + 2 < NP;
+                        stage(same2 ? r0 : r1, same2 ? s + 2 : s + 2 - NP, bcur >= 1 ? bcur - 1 : 2);   // (bcur + 2) % 3
+                    } else {
+                        const bool same = s + 1 < NP;
+                        stage(same ? r0 : r1, same ? s + 1 : 0, (phase + 1) & 1);
+                    }
                     {
                         constexpr int jr = (s + NP - 1) % NP;   // the fragments the previous phase used
     #pragma unroll
@@ -918,7 +934,7 @@ __global__ __launch_bounds__(64 * NW, 4) void conv_mround_mfma_kernel(
                     MST(1);
                     if constexpr (s + 1 < MO) {   // group s + 1 of the previous round: every earlier group is behind a barrier
                         if (pend_g == s + 1) {
-                            rmw(pacc, pend_d4, pend_nv);
+                            rmw(MO == 2 ? acc[0] : pacc, pend_d4, pend_nv);
                             pend_g = 0;
                         }
                     }
@@ -928,18 +944,21 @@ __global__ __launch_bounds__(64 * NW, 4) void conv_mround_mfma_kernel(
                     }
                     MST(2);
                     if (valid)
-                        compute_phase<NT, SLJ, 1, 1, COUT>(wbuf + (size_t)((phase & 1) * MO + gi) * SL * COUT, a_c[s], acc, g, r16);
+                        compute_phase<NT, SLJ, 1, 1, COUT>(wbuf + (size_t)((NB == 3 ? bcur : (phase & 1)) * MO + gi) * SL * COUT, a_c[s], acc, g, r16);
                     MST(3);
                     MST_ADD(8, valid ? 1 : 0);
                     MST_ADD(9, valid ? 0 : 1);
                     phase++;
+                    bcur = bcur == 2 ? 0 : bcur + 1;
                 });
             }
             const int nv = __popcll(__ballot(rowc >= 0) & 0xFFFFull);
             if (valid && gi == 0) rmw(acc[0], ic.d4, nv);
             if (valid && gi > 0) {
+                if (MO > 2) {   // MO == 2: the sums stay in acc, which is cleared only after they have been added (phase 0)
 #pragma unroll
-                for (int nn = 0; nn < NT; nn++) pacc[nn] = acc[0][nn];
+                    for (int nn = 0; nn < NT; nn++) pacc[nn] = acc[0][nn];
+                }
                 pend_g = gi;
                 pend_d4 = ic.d4;
                 pend_nv = nv;
@@ -953,7 +972,7 @@ __global__ __launch_bounds__(64 * NW, 4) void conv_mround_mfma_kernel(
 #pragma unroll
         for (int gq = 1; gq < MO; gq++) {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" SEI_BARRIER_INSN ::: "memory");
-            if (pend_g == gq) rmw(pacc, pend_d4, pend_nv);
+            if (pend_g == gq) rmw(MO == 2 ? acc[0] : pacc, pend_d4, pend_nv);
         }
     }
     __syncthreads();
@@ -1151,36 +1170,51 @@ static bool env_plan(int nOut, int *maxs, int *cs, int *slj, int *blocks, int *n
 
 // sixteen-wave instantiations of the round kernels for NT column tiles and nIn input planes: slj = slice width / 16 (0: none),
 // mo = offsets a round may span (2: conv_round_mfma_kernel; 3 / 4: conv_mround_mfma_kernel, whose LDS holds mo slices per buffer)
-struct Round16 { int slj, mo, fam; };   // fam 2: conv_round_mfma_kernel, 3: conv_mround_mfma_kernel
+struct Round16 { int slj, mo, fam, nb; };   // fam 2: conv_round_mfma_kernel, 3: conv_mround_mfma_kernel; nb: weight buffers
 static Round16 round16_plan(int nt, int nIn) {
-    int mo_cap = 4;
+    int nb = 2;
+    bool long2 = true;
 #ifdef SEI_EXPERIMENTS
+    int mo_cap = 2;
+    bool fam3 = false;   // "SEI_ROUND_FAM=3": conv_mround_mfma_kernel (two offsets, SEI_ROUND_NB buffers) wherever the round kernels run
+    if (const char *e = getenv("SEI_ROUND_FAM")) fam3 = atoi(e) == 3;
     if (const char *e = getenv("SEI_ROUND_MO")) mo_cap = atoi(e);
-    const char *l2 = getenv("SEI_ROUND_LONG");   // "0": the four-phase forms at 64 input planes
-    const bool long2 = !l2 || atoi(l2) != 0;
-#else
-    const bool long2 = true;
+    if (const char *e = getenv("SEI_ROUND_LONG")) long2 = atoi(e) != 0;   // "0": the four-phase forms at 64 input planes
+    if (const char *e = getenv("SEI_ROUND_NB")) nb = atoi(e);
 #endif
     // [r5] 64 input planes: two long phases of 32 planes per round, two offsets (conv_mround_mfma_kernel<NT, 16, 4, 2, 2>)
-    if (long2 && nIn == 64 && (nt == 4 || nt == 6)) return {2, 2, 3};
+    if (long2 && nIn == 64 && (nt == 4 || nt == 6)) return {2, 2, 3, 2};
+#ifdef SEI_EXPERIMENTS
     if (mo_cap >= 3 && nIn % 16 == 0) {
-        // [r5] multi-offset rounds: the widest slice and the most offsets whose buffers fit beside the 256-row tile
-        Round16 r{0, 0, 3};
-        if (nt == 4 && nIn == 64) r = {1, 4, 3};
-        if (nt == 4 && nIn == 96) r = {2, 3, 3};
-        if (nt == 4 && (nIn == 128 || nIn == 160 || nIn == 192)) r = {2, 4, 3};
-        if (nt == 5 && (nIn == 128 || nIn == 160 || nIn == 192)) r = {2, 3, 3};
-        if (nt == 6 && (nIn == 64 || nIn == 96 || nIn == 128)) r = {1, 4, 3};
+        // [r5] multi-offset rounds (measured, not a default: profiles/r05_mround_ab.log): the widest slice and the most offsets
+        // whose buffers fit beside the 256-row tile
+        Round16 r{0, 0, 3, 2};
+        if (nt == 4 && nIn == 64) r = {1, 4, 3, 2};
+        if (nt == 4 && nIn == 96) r = {2, 3, 3, 2};
+        if (nt == 4 && (nIn == 128 || nIn == 160 || nIn == 192)) r = {2, 4, 3, 2};
+        if (nt == 5 && (nIn == 128 || nIn == 160 || nIn == 192)) r = {2, 3, 3, 2};
+        if (nt == 6 && (nIn == 64 || nIn == 96 || nIn == 128)) r = {1, 4, 3, 2};
         if (r.mo > mo_cap) r.mo = mo_cap;
         if (r.slj) return r;
     }
+#endif
     if (nIn % 32 == 0 && nIn >= 96 && nIn <= 192) {
-        if (nt == 6 && (nIn == 96 || nIn == 128)) return {2, 2, 2};
-        if (nt == 4 && (nIn == 96 || nIn == 128 || nIn == 160 || nIn == 192)) return {2, 2, 2};
-        if (nt == 5 && (nIn == 128 || nIn == 160 || nIn == 192)) return {2, 2, 2};
+#ifdef SEI_EXPERIMENTS
+        if (fam3 && ((nt == 6 && nIn <= 128) || nt == 4 || (nt == 5 && nIn >= 128)) && (nb == 2 || nt != 6)) return {2, 2, 3, nb == 3 ? 3 : 2};
+#endif
+        // [r5] level 5 (192 -> 192 planes in 3 x 64-column blocks, 501 workgroups on 256 CUs): the multi-offset kernel in its
+        // two-offset form -- segment table in a lane register (no LDS round trips while a round is planned), staging pieces dealt
+        // over all sixteen waves -- runs 90.2 against 83.4 TFLOP/s; at 96 / 128 / 160 planes the two kernels tie within 1 %
+        // (88.1 / 92.4 / 89.3 against 86.6 / 92.0 / 88.5) and the round-4 kernel stays.  A THIRD weight buffer (slices staged two
+        // phases ahead, SEI_ROUND_NB=3 in experiment builds) changes nothing anywhere: 88.1 / 91.5 / 87.9 / 90.4
+        // (profiles/r05_round_third_buffer_ab.log)
+        if (nt == 4 && nIn == 192) return {2, 2, 3, nb == 3 ? 3 : 2};
+        if (nt == 6 && (nIn == 96 || nIn == 128)) return {2, 2, 2, 2};
+        if (nt == 4 && (nIn == 96 || nIn == 128 || nIn == 160 || nIn == 192)) return {2, 2, 2, 2};
+        if (nt == 5 && (nIn == 128 || nIn == 160 || nIn == 192)) return {2, 2, 2, 2};
     }
-    if (nt == 6 && nIn == 64) return {1, 2, 2};
-    return {0, 0, 0};
+    if (nt == 6 && nIn == 64) return {1, 2, 2, 2};
+    return {0, 0, 0, 2};
 }
 
 // [r5] the 64 -> 64 plane layers of large levels (level 1 of the DUNE network) leave the wave-private kernel for the
@@ -1255,12 +1289,12 @@ static ConvPlan plan_tile(int nIn, int nOut, int K, int64_t n_dst) {
                 // with 32-plane slices -- half the phases, half the weight staging per sub-chunk, padding 0.95 instead of 0.90:
                 // 88.1 / 92.9 / 89.0 against 84.7 / 86.4 / 86.6 TFLOP/s at 96 / 128 / 160 planes (profiles/r04_conv_round_ab.log)
                 const int cols = nOut / p.blocks;
-                const Round16 r16p = K + 1 <= 64 ? round16_plan(cols / 16, nIn) : Round16{0, 0, 0};
+                const Round16 r16p = K + 1 <= 64 ? round16_plan(cols / 16, nIn) : Round16{0, 0, 0, 2};
                 bool wide = r16p.slj > 0;
 #ifdef SEI_EXPERIMENTS
                 if (const char *e = getenv("SEI_ROUND_NW")) wide = wide && atoi(e) == 16;
 #endif
-                if (wide) { p.nw = 16; p.mo = r16p.mo; p.g = r16p.fam; p.slj = r16p.mo * r16p.slj; }   // slj sizes the LDS: mo slices per buffer
+                if (wide) { p.nw = 16; p.mo = r16p.mo; p.g = r16p.fam; p.nb = r16p.nb; p.slj = (r16p.nb * r16p.mo * r16p.slj + 1) / 2; }   // slj sizes the LDS: nb buffers of mo slices
             }
         }
 #ifdef SEI_EXPERIMENTS
@@ -1332,21 +1366,29 @@ static int launch_round(const TiledRules &t, const ConvPlan &p, const float *X, 
     // one register set of A fragments refilled a phase after use (NJ = nIn / 16 > 0) where 128 registers hold it; the narrower
     // column blocks keep the per-phase gathers and three workgroups per CU
     if (p.nw == 16 && p.g == 3) {   // [r5] sixteen-wave rounds spanning up to p.mo offsets / with two long phases (conv_mround_mfma_kernel)
-#define MROUND16(NJ_, SLJ_, MO_)                                                                                           \
-        if (nIn == 16 * NJ_ && p.mo == MO_ && p.slj == MO_ * SLJ_) {                                                       \
-            SEI_TRY(ensure_max_lds((const void *)conv_mround_mfma_kernel<NT, 16, NJ_, SLJ_, MO_>, 160 * 1024));            \
-            conv_mround_mfma_kernel<NT, 16, NJ_, SLJ_, MO_><<<((t.n_tiles * p.blocks + 7) / 8) * 8, 1024, p.lds_bytes, st>>>( \
+#define MROUND16(NJ_, SLJ_, MO_, NB_)                                                                                      \
+        if (nIn == 16 * NJ_ && p.mo == MO_ && p.nb == NB_ && p.slj == (NB_ * MO_ * SLJ_ + 1) / 2) {                         \
+            SEI_TRY(ensure_max_lds((const void *)conv_mround_mfma_kernel<NT, 16, NJ_, SLJ_, MO_, NB_>, 160 * 1024));        \
+            conv_mround_mfma_kernel<NT, 16, NJ_, SLJ_, MO_, NB_><<<((t.n_tiles * p.blocks + 7) / 8) * 8, 1024, p.lds_bytes, st>>>( \
                 X, W, bias, Y, t.tile_sub_start, t.tile_seg, t.sub_src, t.sub_dst, t.n_dst, t.K, nIn, t.n_tiles, init,     \
                 NT * 16 * p.blocks, p.blocks, stats, ep);                                                                  \
             SEI_LAUNCH_CHECK();                                                                                            \
             return 0;                                                                                                      \
         }
-        if constexpr (NT == 4) { MROUND16(4, 2, 2) MROUND16(4, 1, 4) MROUND16(6, 2, 3) MROUND16(8, 2, 4) MROUND16(10, 2, 4) MROUND16(12, 2, 4) }
-        if constexpr (NT == 5) { MROUND16(8, 2, 3) MROUND16(10, 2, 3) MROUND16(12, 2, 3) }
-        if constexpr (NT == 6) { MROUND16(4, 2, 2) MROUND16(4, 1, 4) MROUND16(6, 1, 4) MROUND16(8, 1, 4) }
-#ifdef SEI_EXPERIMENTS   // SEI_ROUND_MO=3
-        if constexpr (NT == 4) { MROUND16(4, 1, 3) MROUND16(8, 2, 3) MROUND16(10, 2, 3) MROUND16(12, 2, 3) }
-        if constexpr (NT == 6) { MROUND16(4, 1, 3) MROUND16(6, 1, 3) MROUND16(8, 1, 3) }
+        if constexpr (NT == 4) { MROUND16(4, 2, 2, 2) MROUND16(12, 2, 2, 2) }
+        if constexpr (NT == 6) { MROUND16(4, 2, 2, 2) }
+#ifdef SEI_EXPERIMENTS   // SEI_ROUND_FAM=3 with SEI_ROUND_NB=2 / 3
+        if constexpr (NT == 4) { MROUND16(6, 2, 2, 2) MROUND16(8, 2, 2, 2) MROUND16(10, 2, 2, 2)
+                                 MROUND16(6, 2, 2, 3) MROUND16(8, 2, 2, 3) MROUND16(10, 2, 2, 3) MROUND16(12, 2, 2, 3) }
+        if constexpr (NT == 5) { MROUND16(8, 2, 2, 2) MROUND16(10, 2, 2, 2) MROUND16(12, 2, 2, 2)
+                                 MROUND16(8, 2, 2, 3) MROUND16(10, 2, 2, 3) MROUND16(12, 2, 2, 3) }
+        if constexpr (NT == 6) { MROUND16(6, 2, 2, 2) MROUND16(8, 2, 2, 2) }
+#endif
+#ifdef SEI_EXPERIMENTS   // SEI_ROUND_MO=3 / 4, SEI_ROUND_LONG=0
+        if constexpr (NT == 4) { MROUND16(4, 1, 4, 2) MROUND16(6, 2, 3, 2) MROUND16(8, 2, 4, 2) MROUND16(10, 2, 4, 2) MROUND16(12, 2, 4, 2)
+                                 MROUND16(4, 1, 3, 2) MROUND16(8, 2, 3, 2) MROUND16(10, 2, 3, 2) MROUND16(12, 2, 3, 2) }
+        if constexpr (NT == 5) { MROUND16(8, 2, 3, 2) MROUND16(10, 2, 3, 2) MROUND16(12, 2, 3, 2) }
+        if constexpr (NT == 6) { MROUND16(4, 1, 4, 2) MROUND16(6, 1, 4, 2) MROUND16(8, 1, 4, 2) MROUND16(4, 1, 3, 2) MROUND16(6, 1, 3, 2) MROUND16(8, 1, 3, 2) }
 #endif
 #undef MROUND16
         SEI_FAIL("conv_forward: no multi-offset round instantiation for this plan");

@@ -85,6 +85,7 @@ class Trainer:
         self.device = device
         self.batch_rulebooks = True   # build a batch's rulebooks up front from the previous batch's list (one read-back)
         self._side = None        # stream of Trainer.prefetch
+        self._ahead = None       # main-stream event recorded at the previous prefetch() call (bounds the host's run-ahead)
         self._template = None    # metadata of the last batch that went through forward(): what prefetch() rebuilds
 
     def _build_optimizer(self, start):
@@ -140,6 +141,16 @@ class Trainer:
         if self._side is None:
             self._side = torch.cuda.Stream()   # default priority (a high-priority build stream measured no different)
         main = torch.cuda.current_stream()
+        # The side stream waits for nothing the main stream does, and the host blocks only on the side stream's count
+        # read-backs: left alone, a loop that never synchronises queues step after step ahead of the GPU, each with its
+        # batch's hash tables and rulebooks alive in the library's pool (bench.py: +9.5 GB over ten steps).  One batch
+        # ahead is all the overlap needs: before the build for step j + 2 starts, the host waits for the END of step j
+        # (the step in front of the one just queued); the GPU still holds a whole queued step, so it never idles.
+        mark = torch.cuda.Event()
+        mark.record(main)
+        if self._ahead is not None:
+            self._ahead.synchronize()
+        self._ahead = mark
         if after is None:
             self._side.wait_stream(main)
         else:
