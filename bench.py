@@ -438,7 +438,7 @@ def main():
                     traffic_src = {"file": "profiles/" + tname, "git_blob": hashlib.sha1(b"blob %d\0" % len(raw) + raw).hexdigest(),
                                    "measured_at_commit": tj.get("commit")}
                 roof = {"bound": "mfma",
-                        "kernel": "conv_round_mfma_kernel + conv_tile_mfma_kernel + conv_wave_mfma_kernel (" +
+                        "kernel": "conv_round_mfma_kernel + conv_mround_mfma_kernel + conv_tile_mfma_kernel + conv_wave_mfma_kernel (" +
                                   ("all FORWARD launches; the dX launches of the same kernels run beside the dW backlog of the "
                                    "side stream by design -- their event durations measure the sharing, see whole_step"
                                    if shared else "all forward + dX launches") + ")",

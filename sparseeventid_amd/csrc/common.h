@@ -383,6 +383,20 @@ int sparse_to_dense(const Level *lv, int batch, const float *feats, int C, float
 int pool_tanh(const Level *lv, int batch, const float *feats, int C, float *out, const float *dout, float *dfeats,
               hipStream_t st);
 
+// Diagnostic build only (make EXTRA="-DSEI_EXPERIMENTS -DSEI_CLOCK"; tools/kernel_clock.py): the shader clock a kernel HOLDS while
+// it runs (MI355X_MICROARCH.md, DVFS give-back item 6): wave 0 of every workgroup adds the s_memtime ticks (shader cycles) and
+// the s_memrealtime ticks (100 MHz) of its lifetime to g_clk[family]; clock = 100 MHz x sum(memtime) / sum(memrealtime).
+// The stamps go to a buffer nothing else reads; the product build compiles none of it.
+#ifdef SEI_CLOCK
+// (one array per translation unit: device symbols do not link across objects without relocatable device code)
+#define CLK_BEGIN unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime()
+#define CLK_END(fam) do { if (threadIdx.x == 0) { atomicAdd(&g_clk[fam][0], __builtin_amdgcn_s_memtime() - clk_t0); \
+                                                  atomicAdd(&g_clk[fam][1], __builtin_amdgcn_s_memrealtime() - clk_r0); } } while (0)
+#else
+#define CLK_BEGIN
+#define CLK_END(fam)
+#endif
+
 // ---- profiling (HIP events around launches) ----
 // kinds 6 / 7: forward / dX launches of the 32 -> 32 plane layers (level 0 of the DUNE network), kept apart because they
 // are priced against the HBM roofline, not the MFMA one

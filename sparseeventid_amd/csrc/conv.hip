@@ -16,6 +16,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ inline f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
+#ifdef SEI_CLOCK
+__device__ unsigned long long g_clk[8][2];   // family 2: conv_dw_mfma_kernel (sei_debug_clock_dw)
+#endif
+
 // position of column c inside a column group of NT = width/16 tiles (see load_b in conv_fwd.hip)
 __device__ inline int permute_col(int c, int width) {
     if (width == 0) return c;
@@ -249,6 +253,7 @@ __global__ __launch_bounds__(256, dw_min_waves(MT, NT)) void conv_dw_mfma_kernel
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r16 = lane & 15, g = lane >> 4;
     const int ci0 = cig * MT * 16;
+    CLK_BEGIN;
     f32x4 acc[MT][NT];
 #pragma unroll
     for (int m = 0; m < MT; m++)
@@ -316,6 +321,7 @@ __global__ __launch_bounds__(256, dw_min_waves(MT, NT)) void conv_dw_mfma_kernel
     }
     float *out = slab + ((size_t)(k * S + s) * CIN + ci0) * COUT;
     for (int idx = threadIdx.x; idx < MT * 16 * COUT; idx += 256) out[idx] = red[idx];
+    CLK_END(2);
 }
 
 #ifdef SEI_EXPERIMENTS
@@ -897,3 +903,14 @@ int dw_ring_timeouts(int *out, bool reset) {
 }
 
 }  // namespace sei
+
+#ifdef SEI_CLOCK
+extern "C" int sei_debug_clock_dw(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(sei::g_clk), sizeof(sei::g_clk)) != hipSuccess) return 1;
+    if (reset) {
+        static unsigned long long z[8][2] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(sei::g_clk), z, sizeof(z)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif

@@ -29,6 +29,10 @@
 
 namespace sei {
 
+#ifdef SEI_CLOCK
+__device__ unsigned long long g_clk[8][2];   // families 0 (conv_round_mfma_kernel) and 1 (conv_mround_mfma_kernel)
+#endif
+
 // Diagnostic build only (make EXTRA=-DSEI_STAMPS; tools/stamps.py): wave 1 of every tile adds the s_memtime
 // ticks it spends in each part of the forward kernel to g_stamps.  The product build compiles none of it.
 #ifdef SEI_STAMPS
@@ -444,6 +448,7 @@ __global__ __launch_bounds__(64 * NW, (NJ > 0 ? 4 : occ8_for(NT, 1, 2, 1))) void
     float *acc_tile = lds;
     float *wbuf = lds + (size_t)TR * COUT;   // [buffer][offset half][SL][COUT]
     int *seg = reinterpret_cast<int *>(wbuf + 4 * SL * COUT);
+    CLK_BEGIN;
 
     TRACE_DECL;
     for (int i = threadIdx.x; i <= K; i += 64 * NW) seg[i] = tile_seg[(size_t)tile * (K + 1) + i];
@@ -644,6 +649,7 @@ __global__ __launch_bounds__(64 * NW, (NJ > 0 ? 4 : occ8_for(NT, 1, 2, 1))) void
     tile_store<TR, COUT, 64 * NW>(acc_tile, Y, row0, n_dst, ldy, ycol0, ep);
     if (stats) tile_stats<TR, COUT, 64 * NW>(acc_tile, stats, tile, row0, n_dst, ldy, ycol0);
     TRACE_END;
+    CLK_END(0);
 }
 
 // ------------------------------------------------------------------------------------------ multi-offset rounds  [r5]
@@ -687,7 +693,12 @@ struct MRound {
 // NB: weight buffers (NP >= 3 only).  2: the slices of phase p + 1 are staged in phase p and have ONE phase to land; 3: those of
 // phase p + 2, TWO phases (the third buffer is the LDS the 128 / 160 / 192-column plans leave unused; every wave then issues the
 // same number of pieces per phase -- surplus ones repeat a neighbour's -- so that the counted vmcnt waits stay exact).
-template <int NT, int NW, int NJ, int SLJ, int MO, int NB = 2>
+// LATE (NB == 3 only; experiment builds): waves NW/2 .. NW-1 issue their requests of a phase BEHIND its MFMA block instead of in
+// front of it.  After a barrier all sixteen waves issue their staging pieces, gathers and index loads at once; the CU's one
+// vector-memory path takes them one after the other, and the waves served last start their MFMAs last (in-kernel stamps: the
+// upper waves spend 35-40 % of their time in the issue section, the lower ones 8 %).  With every request two phases ahead of
+// its use (third weight buffer, refilled fragments) half the waves can compute first.
+template <int NT, int NW, int NJ, int SLJ, int MO, int NB = 2, bool LATE = false>
 __global__ __launch_bounds__(64 * NW, 4) void conv_mround_mfma_kernel(
     const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ Y,
     const int32_t *__restrict__ tile_sub_start, const int32_t *__restrict__ tile_seg,
@@ -698,6 +709,7 @@ __global__ __launch_bounds__(64 * NW, 4) void conv_mround_mfma_kernel(
     static_assert(NJ % SLJ == 0 && NP >= 2, "NP >= 3: the refilled-fragment schedule; NP == 2: two long phases per round");
     static_assert(MO >= 2 && MO <= 4 && MO <= NP, "group g of a round is written back in phase g - 1 of the next one");
     static_assert(NB == 2 || (NB == 3 && NP >= 3), "the third weight buffer belongs to the refilled-fragment schedule");
+    static_assert(!LATE || NB == 3, "requests behind the MFMA block need everything two phases ahead");
     constexpr int TR = 16 * NW, SL = 16 * SLJ, COUT = NT * 16, PIECES = SL * COUT / 256;
     static_assert((SL * COUT) % 256 == 0, "a slice is a whole number of 1-KiB LDS-DMA pieces");
     constexpr int STAGE_PER = (MO * PIECES + NW - 1) / NW;   // pieces a wave issues per staged phase (NB == 3: exactly)
@@ -712,6 +724,7 @@ __global__ __launch_bounds__(64 * NW, 4) void conv_mround_mfma_kernel(
     float *acc_tile = lds;
     float *wbuf = lds + (size_t)TR * COUT;   // [buffer][group][SL][COUT]
     MST_DECL;
+    CLK_BEGIN;
 
     // segment table: lane i holds seg[i] (i <= K < 64); bit i of `nonempty`: offset i has sub-chunks in this tile
     const int32_t *segp = tile_seg + (size_t)tile * (K + 1);
@@ -912,25 +925,29 @@ __global__ __launch_bounds__(64 * NW, 4) void conv_mround_mfma_kernel(
                         for (int jj = 0; jj < SLJ; jj++)
                             asm volatile("" : "+v"(a_c[jg][0][jj].x), "+v"(a_c[jg][0][jj].y), "+v"(a_c[jg][0][jj].z), "+v"(a_c[jg][0][jj].w));
                     }
-                    if (NB == 3) {
-                        const bool same2 = s + 2 < NP;
-                        stage(same2 ? r0 : r1, same2 ? s + 2 : s + 2 - NP, bcur >= 1 ? bcur - 1 : 2);   // (bcur + 2) % 3
-                    } else {
-                        const bool same = s + 1 < NP;
-                        stage(same ? r0 : r1, same ? s + 1 : 0, (phase + 1) & 1);
-                    }
-                    {
-                        constexpr int jr = (s + NP - 1) % NP;   // the fragments the previous phase used
+                    auto requests = [&]() {
+                        if (NB == 3) {
+                            const bool same2 = s + 2 < NP;
+                            stage(same2 ? r0 : r1, same2 ? s + 2 : s + 2 - NP, bcur >= 1 ? bcur - 1 : 2);   // (bcur + 2) % 3
+                        } else {
+                            const bool same = s + 1 < NP;
+                            stage(same ? r0 : r1, same ? s + 1 : 0, (phase + 1) & 1);
+                        }
+                        {
+                            constexpr int jr = (s + NP - 1) % NP;   // the fragments the previous phase used
     #pragma unroll
-                        for (int jj = 0; jj < SLJ; jj++)
-                            a_c[jr][0][jj] = load_a(X, s == 0 ? rowc : rown, CIN, 16 * (SLJ * jr + jj) + 4 * g);
-                        asm volatile("" ::: "memory");
-                    }
-                    if (s == IDXP) {
-                        r3 = plan(r2.q0 + cnt_of(r2), last_of(r2));
-                        i3 = load_idx(r3);
-                        asm volatile("" ::: "memory");
-                    }
+                            for (int jj = 0; jj < SLJ; jj++)
+                                a_c[jr][0][jj] = load_a(X, s == 0 ? rowc : rown, CIN, 16 * (SLJ * jr + jj) + 4 * g);
+                            asm volatile("" ::: "memory");
+                        }
+                        if (s == IDXP) {
+                            r3 = plan(r2.q0 + cnt_of(r2), last_of(r2));
+                            i3 = load_idx(r3);
+                            asm volatile("" ::: "memory");
+                        }
+                    };
+                    const bool late = LATE && wave >= NW / 2;   // wave-uniform
+                    if (!late) requests();
                     MST(1);
                     if constexpr (s + 1 < MO) {   // group s + 1 of the previous round: every earlier group is behind a barrier
                         if (pend_g == s + 1) {
@@ -945,6 +962,7 @@ __global__ __launch_bounds__(64 * NW, 4) void conv_mround_mfma_kernel(
                     MST(2);
                     if (valid)
                         compute_phase<NT, SLJ, 1, 1, COUT>(wbuf + (size_t)((NB == 3 ? bcur : (phase & 1)) * MO + gi) * SL * COUT, a_c[s], acc, g, r16);
+                    if (late) requests();
                     MST(3);
                     MST_ADD(8, valid ? 1 : 0);
                     MST_ADD(9, valid ? 0 : 1);
@@ -983,6 +1001,7 @@ __global__ __launch_bounds__(64 * NW, 4) void conv_mround_mfma_kernel(
     MST(7);
     MST_ADD(11, 1);
     MST_FLUSH;
+    CLK_END(1);
 }
 
 // Stem-type convolutions (tiny nIn, e.g. 1 -> 32 with 125 offsets): all of W sits in LDS, lane = output plane so that
@@ -1366,6 +1385,20 @@ static int launch_round(const TiledRules &t, const ConvPlan &p, const float *X, 
     // one register set of A fragments refilled a phase after use (NJ = nIn / 16 > 0) where 128 registers hold it; the narrower
     // column blocks keep the per-phase gathers and three workgroups per CU
     if (p.nw == 16 && p.g == 3) {   // [r5] sixteen-wave rounds spanning up to p.mo offsets / with two long phases (conv_mround_mfma_kernel)
+#ifdef SEI_EXPERIMENTS   // SEI_ROUND_LATE=1 (with SEI_ROUND_FAM=3 SEI_ROUND_NB=3): the upper eight waves issue their requests behind the MFMAs
+#define MROUND16L(NJ_)                                                                                                     \
+        if (nIn == 16 * NJ_ && p.mo == 2 && p.nb == 3 && getenv("SEI_ROUND_LATE") && atoi(getenv("SEI_ROUND_LATE"))) {       \
+            SEI_TRY(ensure_max_lds((const void *)conv_mround_mfma_kernel<NT, 16, NJ_, 2, 2, 3, true>, 160 * 1024));          \
+            conv_mround_mfma_kernel<NT, 16, NJ_, 2, 2, 3, true><<<((t.n_tiles * p.blocks + 7) / 8) * 8, 1024, p.lds_bytes, st>>>( \
+                X, W, bias, Y, t.tile_sub_start, t.tile_seg, t.sub_src, t.sub_dst, t.n_dst, t.K, nIn, t.n_tiles, init,     \
+                NT * 16 * p.blocks, p.blocks, stats, ep);                                                                  \
+            SEI_LAUNCH_CHECK();                                                                                            \
+            return 0;                                                                                                      \
+        }
+        if constexpr (NT == 4) { MROUND16L(8) MROUND16L(10) MROUND16L(12) }
+        if constexpr (NT == 5) { MROUND16L(10) }
+#undef MROUND16L
+#endif
 #define MROUND16(NJ_, SLJ_, MO_, NB_)                                                                                      \
         if (nIn == 16 * NJ_ && p.mo == MO_ && p.nb == NB_ && p.slj == (NB_ * MO_ * SLJ_ + 1) / 2) {                         \
             SEI_TRY(ensure_max_lds((const void *)conv_mround_mfma_kernel<NT, 16, NJ_, SLJ_, MO_, NB_>, 160 * 1024));        \
@@ -1403,9 +1436,13 @@ static int launch_round(const TiledRules &t, const ConvPlan &p, const float *X, 
             SEI_LAUNCH_CHECK();                                                                                          \
             return 0;                                                                                                    \
         }
-        if constexpr (NT == 6) { ROUND16(6, 2) ROUND16(8, 2) ROUND16(4, 1) }
-        if constexpr (NT == 4) { ROUND16(6, 2) ROUND16(8, 2) ROUND16(10, 2) ROUND16(12, 2) }
+        if constexpr (NT == 6) { ROUND16(6, 2) ROUND16(8, 2) }
+        if constexpr (NT == 4) { ROUND16(6, 2) ROUND16(8, 2) ROUND16(10, 2) }
         if constexpr (NT == 5) { ROUND16(8, 2) ROUND16(10, 2) ROUND16(12, 2) }
+#ifdef SEI_EXPERIMENTS   // the plans conv_mround_mfma_kernel took over in round 5 (SEI_ROUND_LONG=0, SEI_ROUND_FAM unset ...)
+        if constexpr (NT == 6) { ROUND16(4, 1) }
+        if constexpr (NT == 4) { ROUND16(12, 2) }
+#endif
 #undef ROUND16
         SEI_FAIL("conv_forward: no sixteen-wave round instantiation for this plan");
     }
@@ -1571,6 +1608,17 @@ int conv_forward(const TiledRules &t, const float *X, const float *W, const floa
 extern "C" int sei_debug_band_timeouts(int32_t *out, int32_t reset) {
     (void)reset;
     if (out) *out = 0;   // no polled hand-off in the shipped library
+    return 0;
+}
+#endif
+
+#ifdef SEI_CLOCK
+extern "C" int sei_debug_clock(unsigned long long *out, int reset) {   // [8 families][memtime ticks, memrealtime ticks]
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(sei::g_clk), sizeof(sei::g_clk)) != hipSuccess) return 1;
+    if (reset) {
+        static unsigned long long z[8][2] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(sei::g_clk), z, sizeof(z)) != hipSuccess) return 1;
+    }
     return 0;
 }
 #endif

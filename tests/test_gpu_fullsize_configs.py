@@ -159,6 +159,14 @@ def test_dune3d_default_net_training_step_64_events(dune_batch64):
             if not pname.endswith("conv1.bias"):
                 assert float(gp.abs().max()) > 0, pname
         runs[name] = (loss1.clone(), loss2.clone(), grad1, tr.arena.flat.clone(), {k: v.detach().clone() for k, v in logits1.items()})
+        # memory ceiling of one 64-event rank (round-4 review): the library's pool held 36.7 GB and torch reserved 44 GB in
+        # round 4; with the host's run-ahead bounded the pool stays below 16 GB.  288 GB per GPU is not a licence to grow.
+        import ctypes
+        from sparseeventid_amd._lib import lib
+        held, used = ctypes.c_int64(), ctypes.c_int64()
+        lib().sei_pool_stats(ctypes.byref(held), ctypes.byref(used))
+        assert held.value < 40e9, held.value / 1e9
+        assert torch.cuda.max_memory_reserved() < 80e9, torch.cuda.max_memory_reserved() / 1e9
         del tr, image, lab, nxt, logits1
         gc.collect()
         torch.cuda.empty_cache()

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import scn_cpu
-from tests.util import blob_cloud, random_cloud, rel_err, sort_rows
+from tests.util import blob_cloud, elem_close, random_cloud, rel_err, sort_rows
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -158,6 +158,11 @@ def test_subm_conv_forward_backward(ci, co, filt, kernel, force_conv_kernel):
     assert rel_err(conv.weight.grad, W.grad) < TOL
     assert rel_err(conv.bias.grad, b.grad) < TOL
     assert rel_err(f.grad, fo.grad) < TOL
+    # and element by element (round-4 review: rel_err is a max-norm ratio): every output / input-gradient element within
+    # 1e-4 of the oracle's, with an absolute floor for elements that are themselves a cancellation of the row's products
+    for got, want in ((out.features, oo.features), (f.grad, fo.grad)):
+        ok, worst = elem_close(got, want, rtol=1e-4, atol=2e-5 * float(want.abs().max()))
+        assert ok, worst
 
 
 @pytest.mark.parametrize("kernel", ["default", "tile", "wave", "band", "rounds"])
@@ -188,6 +193,9 @@ def test_strided_conv_forward_backward(ci, co, size, kernel, force_conv_kernel):
     assert rel_err(out.features, oo.features) < TOL
     assert rel_err(conv.weight.grad, W.grad) < TOL
     assert rel_err(f.grad, fo.grad) < TOL
+    for got, want in ((out.features, oo.features), (f.grad, fo.grad)):
+        ok, worst = elem_close(got, want, rtol=1e-4, atol=2e-5 * float(want.abs().max()))
+        assert ok, worst
 
 
 @pytest.mark.parametrize("C,leak,with_res", [(32, 1.0, False), (32, 1 / 3, False), (96, 1 / 3, True), (7, 0.0, False),
