@@ -1219,6 +1219,8 @@ static Round16 round16_plan(int nt, int nIn) {
 #endif
     if (nIn % 32 == 0 && nIn >= 96 && nIn <= 192) {
 #ifdef SEI_EXPERIMENTS
+        // "SEI_ROUND_L2_SLJ1=1": level 2 with 16-plane slices (120 KB of LDS instead of 144: room for a co-resident dW workgroup)
+        if (nt == 6 && nIn == 96 && getenv("SEI_ROUND_L2_SLJ1") && atoi(getenv("SEI_ROUND_L2_SLJ1"))) return {1, 2, 3, 2};
         if (fam3 && ((nt == 6 && nIn <= 128) || nt == 4 || (nt == 5 && nIn >= 128)) && (nb == 2 || nt != 6)) return {2, 2, 3, nb == 3 ? 3 : 2};
 #endif
         // [r5] level 5 (192 -> 192 planes in 3 x 64-column blocks, 501 workgroups on 256 CUs): the multi-offset kernel in its
@@ -1415,7 +1417,7 @@ static int launch_round(const TiledRules &t, const ConvPlan &p, const float *X, 
                                  MROUND16(6, 2, 2, 3) MROUND16(8, 2, 2, 3) MROUND16(10, 2, 2, 3) MROUND16(12, 2, 2, 3) }
         if constexpr (NT == 5) { MROUND16(8, 2, 2, 2) MROUND16(10, 2, 2, 2) MROUND16(12, 2, 2, 2)
                                  MROUND16(8, 2, 2, 3) MROUND16(10, 2, 2, 3) MROUND16(12, 2, 2, 3) }
-        if constexpr (NT == 6) { MROUND16(6, 2, 2, 2) MROUND16(8, 2, 2, 2) }
+        if constexpr (NT == 6) { MROUND16(6, 2, 2, 2) MROUND16(8, 2, 2, 2) MROUND16(6, 1, 2, 2) }
 #endif
 #ifdef SEI_EXPERIMENTS   // SEI_ROUND_MO=3 / 4, SEI_ROUND_LONG=0
         if constexpr (NT == 4) { MROUND16(4, 1, 4, 2) MROUND16(6, 2, 3, 2) MROUND16(8, 2, 4, 2) MROUND16(10, 2, 4, 2) MROUND16(12, 2, 4, 2)

@@ -187,10 +187,60 @@ __device__ __forceinline__ void wgroup(const float *__restrict__ X, const float 
     WSTAMP_ADD(10, MS);
 }
 
+// [r5] 32 input planes (NS == 2: level 0 of the DUNE network).  wgroup above requests a slice ONE slice ahead of its use: 16 MFMAs
+// (512 pipe cycles) of cover for gathers that come from beyond the L2 -- at ~10 waves per CU the wave then waits ~3000 cycles per
+// slice (197 k cycles per 128-row tile against 23 k of MFMA work).  Here BOTH slices of the NEXT group are requested before this
+// group's first MFMA: a whole group (32 MFMAs + the tile read-modify-write) of cover, two operand sets (cur / nxt) that the
+// caller swaps between groups (no register copies).  Every request is unconditional (a missing sub-chunk re-reads row 0): the
+// number of requests in flight is then a compile-time constant and hipcc's own vmcnt waits stay exact.
+template <int NT, int G, int MS>
+__device__ __forceinline__ void wgroup2(const float *__restrict__ X, const float *__restrict__ wl, int ldy, int CIN, int kn,
+                                        const int (&rc)[G], const int (&rn)[G], const uint32_t (&d4)[G], const int (&src)[G],
+                                        float *acc_tile, int g, int r16, const float4 (&ac0)[G], const float (&bc0)[4][NT],
+                                        const float4 (&ac1)[G], const float (&bc1)[4][NT], float4 (&an0)[G], float (&bn0)[4][NT],
+                                        float4 (&an1)[G], float (&bn1)[4][NT], WStamp &st) {
+    constexpr int NC = 16 * NT;
+    f32x4 acc[MS][NT];
+#pragma unroll
+    for (int m = 0; m < MS; m++)
+#pragma unroll
+        for (int n = 0; n < NT; n++) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+#pragma unroll
+        for (int m = 0; m < G; m++) (j == 0 ? an0 : an1)[m] = wload_a<SEI_WAVE_ABL>(X, rn[m], CIN, 16 * j + 4 * g);
+        const float *wn = wl + ((size_t)kn * CIN + 16 * j) * ldy;
+#pragma unroll
+        for (int e = 0; e < 4; e++) wload_b<NT>(wn + (size_t)e * ldy, r16, (j == 0 ? bn0 : bn1)[e]);
+    }
+    __builtin_amdgcn_sched_barrier(0);   // the requests are ISSUED before this group's MFMAs
+    WSTAMP(1);
+    wslice<NT, G, MS>(ac0, bc0, rc, acc);
+    wslice<NT, G, MS>(ac1, bc1, rc, acc);
+    WSTAMP(2);
+    WSTAMP_ADD(8, 2 * 4 * MS * NT);
+#pragma unroll
+    for (int m = 0; m < MS; m++) {
+        const int nv = __popcll(__ballot(src[m] >= 0) & 0xFFFFull);
+        wrmw<NT>(acc_tile, NC, d4[m], nv, g, r16, acc[m]);
+    }
+    WSTAMP(3);
+    WSTAMP_ADD(9, 1);
+    WSTAMP_ADD(10, MS);
+}
+
+#ifndef SEI_WAVE_GROUP_AHEAD
+#define SEI_WAVE_GROUP_AHEAD 1
+#endif
+constexpr bool GROUP_AHEAD = SEI_WAVE_GROUP_AHEAD != 0;   // experiment builds: -DSEI_WAVE_GROUP_AHEAD=0 = round 2's one-slice-ahead form at 32 planes
+
 constexpr int wave_occ(int nt, int g) {
     // waves per SIMD the register allocator should aim for: accumulators + RMW temporaries + two A and two B
     // slice sets + ~48 registers of addressing / indices (the LDS tile decides the real occupancy)
-    const int est = g * nt * 4 + nt * 4 + 2 * g * 4 + 2 * 4 * nt + 48;
+    // [r5] + the second operand pair of the group-ahead form (32 input planes): LDS holds ~10 waves per CU at 16 KB each, so
+    // three waves per SIMD (168 registers) cost no occupancy, while four (128) spilled 52 registers there
+    const int est = g * nt * 4 + nt * 4 + 2 * g * 4 + 2 * 4 * nt + 48 + (SEI_WAVE_GROUP_AHEAD && nt <= 2 ? 2 * (g * 4 + 4 * nt) : 0);
+    if (SEI_WAVE_GROUP_AHEAD && nt <= 2 && est <= 160) return 3;
     return est <= 120 ? 4 : (est <= 160 ? 3 : (est <= 248 ? 2 : 1));
 }
 
@@ -281,6 +331,53 @@ __global__ __launch_bounds__(64, wave_occ(NT, G)) void conv_wave_mfma_kernel(
         __syncthreads();  // single-wave workgroup: orders the tile initialisation before the first read-modify-write
         WSTAMP(0);
 
+        bool ahead = false;
+        if constexpr (GROUP_AHEAD && NT <= 2) ahead = NS == 2;   // the 32-column kernels only: wider ones would pay for the second operand pair in registers
+        if (ahead) {
+          if constexpr (GROUP_AHEAD && NT <= 2) {
+            // two operand sets, swapped between groups: P holds this group's two slices, Q receives the next group's
+            float4 pa1[G], qa0[G], qa1[G];
+            float pb1[4][NT], qb0[4][NT], qb1[4][NT];
+            {
+                int r0[G];
+#pragma unroll
+                for (int m = 0; m < G; m++) r0[m] = ix0.row(m);
+#pragma unroll
+                for (int m = 0; m < G; m++) pa1[m] = wload_a<SEI_WAVE_ABL>(X, r0[m], CIN, 16 + 4 * g);
+                const float *wn = wl + ((size_t)it0.k * CIN + 16) * ldy;
+#pragma unroll
+                for (int e = 0; e < 4; e++) wload_b<NT>(wn + (size_t)e * ldy, r16, pb1[e]);
+#pragma unroll
+                for (int m = 0; m < G; m++) a0[m] = wload_a<SEI_WAVE_ABL>(X, r0[m], CIN, 4 * g);   // every sub-chunk slot (wprefetch skipped the missing ones)
+            }
+            bool flip = false;
+            while (it0.k < K) {
+                const int kn = it1.k < K ? it1.k : it0.k;
+                int rc[G], rn[G];
+#pragma unroll
+                for (int m = 0; m < G; m++) {
+                    rc[m] = ix0.row(m);
+                    rn[m] = ix1.row(m);
+                }
+#define WGROUP2(MS_)                                                                                                         \
+                do {                                                                                                         \
+                    if (!flip) wgroup2<NT, G, (MS_ <= G ? MS_ : 1)>(X, wl, ldy, CIN, kn, rc, rn, ix0.d4, ix0.src, acc_tile, g, r16, \
+                                                                     a0, b0, pa1, pb1, qa0, qb0, qa1, qb1, st);              \
+                    else wgroup2<NT, G, (MS_ <= G ? MS_ : 1)>(X, wl, ldy, CIN, kn, rc, rn, ix0.d4, ix0.src, acc_tile, g, r16,  \
+                                                               qa0, qb0, qa1, qb1, a0, b0, pa1, pb1, st);                    \
+                } while (0)
+                if (G == 1 || ix0.cnt == 1) WGROUP2(1);
+                else if (G == 2 || ix0.cnt == 2) WGROUP2(2);
+                else if (G == 3 || ix0.cnt == 3) WGROUP2(3);
+                else WGROUP2(4);
+#undef WGROUP2
+                flip = !flip;
+                it0 = it1; it1 = it2; it2 = advance(it2);
+                ix0 = ix1; ix1 = ix2; ix2 = load_idx(it2);
+                WSTAMP(4);
+            }
+          }
+        } else
         while (it0.k < K) {
             const int kn = it1.k < K ? it1.k : it0.k;  // weights prefetched after the last slice (unused at the very end)
             int rc[G], rn[G];
