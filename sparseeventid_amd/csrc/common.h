@@ -301,6 +301,7 @@ struct ConvPlan {
     int blocks = 1;      // column blocks (kind 1: weights stored as [block][K][nIn][nOut/blocks])
     int nt = 0, cs = 0, slj = 0, maxs = 0, g = 0;   // kind 1, g == 2: two-offset rounds (conv_round_mfma_kernel), g == 3: with refilled A fragments
     int nw = 4;          // kind 1: waves per workgroup (4, 8 or 16)
+    bool persist = false; // kind 1, g == 3: one workgroup per CU walks the work items (conv_mround_mfma_kernel<.., PERSIST>)
     int nb = 2;          // kind 1, g == 3: weight buffers of the round kernel (3: slices staged two phases ahead)
     int mo = 0;          // kind 1, g == 2 / 3, nw == 16: offsets a round may span (2: conv_round_mfma_kernel, 3 / 4: conv_mround_mfma_kernel)
     size_t lds_bytes = 0;

@@ -117,12 +117,12 @@ __device__ __forceinline__ void load_b(const float *__restrict__ wrow, int r16, 
         const float4 v = *reinterpret_cast<const float4 *>(wrow + 64 * q + 4 * r16);
         b[4 * q + 0] = v.x; b[4 * q + 1] = v.y; b[4 * q + 2] = v.z; b[4 * q + 3] = v.w;
     }
-    if (REM >= 2) {
+    if constexpr (REM >= 2) {
         const float2 v = *reinterpret_cast<const float2 *>(wrow + 64 * B4 + 2 * r16);
         b[4 * B4 + 0] = v.x; b[4 * B4 + 1] = v.y;
     }
-    if (REM == 1) b[4 * B4] = wrow[64 * B4 + r16];
-    if (REM == 3) b[4 * B4 + 2] = wrow[64 * B4 + 32 + r16];
+    if constexpr (REM == 1) b[4 * B4] = wrow[64 * B4 + r16];
+    if constexpr (REM == 3) b[4 * B4 + 2] = wrow[64 * B4 + 32 + r16];
 }
 
 // one (k, slice) phase for a wave owning MS sub-chunks: straight-line, so the LDS reads of step
@@ -698,12 +698,18 @@ struct MRound {
 // vector-memory path takes them one after the other, and the waves served last start their MFMAs last (in-kernel stamps: the
 // upper waves spend 35-40 % of their time in the issue section, the lower ones 8 %).  With every request two phases ahead of
 // its use (third weight buffer, refilled fragments) half the waves can compute first.
-template <int NT, int NW, int NJ, int SLJ, int MO, int NB = 2, bool LATE = false>
+// PERSIST [r5]: one workgroup per CU walks MANY work items (tile, column block).  With one sixteen-wave workgroup per CU nothing
+// runs beside a workgroup's prologue -- segment table -> round plans -> index words -> first gathers, three dependent trips to
+// memory, ~5 % of a level-1 tile -- so the NEXT item's ticket (one atomic counter per XCD, `work`: the items keep the XCD-aware
+// order of xcd_item), its segment table, its first three round plans and their index words are requested while the current tile
+// computes (one step per round, `prefetch_step`); what stays exposed at a tile boundary is the tile's store, the next tile's
+// initialisation and ONE trip (the first gathers).  Same rounds, same order of sums: bit-identical.
+template <int NT, int NW, int NJ, int SLJ, int MO, int NB = 2, bool LATE = false, bool PERSIST = false>
 __global__ __launch_bounds__(64 * NW, 4) void conv_mround_mfma_kernel(
     const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ Y,
     const int32_t *__restrict__ tile_sub_start, const int32_t *__restrict__ tile_seg,
     const int32_t *__restrict__ sub_src, const uint8_t *__restrict__ sub_dst, int64_t n_dst, int K, int CIN, int n_tiles,
-    const float *__restrict__ init, int ldy, int blocks, double *__restrict__ stats, ConvEpilogue ep) {
+    const float *__restrict__ init, int ldy, int blocks, double *__restrict__ stats, ConvEpilogue ep, int *__restrict__ work) {
     extern __shared__ float lds[];
     constexpr int NP = NJ / SLJ;   // phases of a round
     static_assert(NJ % SLJ == 0 && NP >= 2, "NP >= 3: the refilled-fragment schedule; NP == 2: two long phases per round");
@@ -713,47 +719,78 @@ __global__ __launch_bounds__(64 * NW, 4) void conv_mround_mfma_kernel(
     constexpr int TR = 16 * NW, SL = 16 * SLJ, COUT = NT * 16, PIECES = SL * COUT / 256;
     static_assert((SL * COUT) % 256 == 0, "a slice is a whole number of 1-KiB LDS-DMA pieces");
     constexpr int STAGE_PER = (MO * PIECES + NW - 1) / NW;   // pieces a wave issues per staged phase (NB == 3: exactly)
-    const int vid = xcd_item(n_tiles * blocks);
-    if (vid >= n_tiles * blocks) return;
-    const int tile = vid / blocks, cblk = vid - tile * blocks;
-    W += (size_t)cblk * K * CIN * COUT;
-    if (bias) bias += cblk * COUT;
-    const int ycol0 = cblk * COUT;
+    const int n_items = n_tiles * blocks;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r16 = lane & 15, g = lane >> 4;
     float *acc_tile = lds;
     float *wbuf = lds + (size_t)TR * COUT;   // [buffer][group][SL][COUT]
+    int *lds_ticket = reinterpret_cast<int *>(wbuf + (size_t)NB * MO * SL * COUT);   // PERSIST: the next item's ticket, wave 0 -> all
     MST_DECL;
     CLK_BEGIN;
 
-    // segment table: lane i holds seg[i] (i <= K < 64); bit i of `nonempty`: offset i has sub-chunks in this tile
-    const int32_t *segp = tile_seg + (size_t)tile * (K + 1);
-    const int segv = segp[lane < K ? lane : K], segn = segp[lane + 1 < K ? lane + 1 : K];
-    const unsigned long long nonempty = __ballot(segn > segv);
-    auto seg_at = [&](int i) { return __builtin_amdgcn_readlane(segv, __builtin_amdgcn_readfirstlane(i)); };
-    auto next_nonempty = [&](int c) {   // smallest nonempty offset > c (K if none); c in [-1, K)
-        const unsigned long long m = nonempty >> (c + 1);
+    // One work item's segment table: lane i holds seg[i] (i <= K < 64); bit i of `nonempty`: offset i has sub-chunks in the tile
+    struct Ctx { int segv; unsigned long long nonempty; int n; int sub0; };
+    struct CtxReq { int segv, segn, sub0; };
+    auto ctx_request = [&](int vid) {   // loads only
+        const int tl = vid / blocks;
+        const int32_t *segp = tile_seg + (size_t)tl * (K + 1);
+        CtxReq q;
+        q.segv = segp[lane < K ? lane : K];
+        q.segn = segp[lane + 1 < K ? lane + 1 : K];
+        q.sub0 = tile_sub_start[tl];
+        return q;
+    };
+    auto ctx_finish = [&](const CtxReq &q) {
+        Ctx c;
+        c.segv = q.segv;
+        c.nonempty = __ballot(q.segn > q.segv);
+        c.n = __builtin_amdgcn_readlane(q.segv, __builtin_amdgcn_readfirstlane(K));
+        c.sub0 = __builtin_amdgcn_readfirstlane(q.sub0);
+        return c;
+    };
+    auto seg_at = [&](const Ctx &cx, int i) { return __builtin_amdgcn_readlane(cx.segv, __builtin_amdgcn_readfirstlane(i)); };
+    auto next_nonempty = [&](const Ctx &cx, int c) {   // smallest nonempty offset > c (K if none); c in [-1, K)
+        const unsigned long long m = cx.nonempty >> (c + 1);
         return m ? c + 1 + (int)__builtin_ctzll(m) : K;
     };
-    tile_init<TR, COUT, 64 * NW>(acc_tile, bias, init, (int64_t)tile * TR, n_dst, ldy, ycol0);
-    __syncthreads();
-
-    const int64_t sub0 = tile_sub_start[tile];
-    const int n = seg_at(K);
+    // PERSIST: tickets of this workgroup's XCD -> work items in the order of xcd_item (conv_tile.h); n_items when the XCD's share is used up
+    const int xcd = blockIdx.x & 7;
+    auto item_of = [&](int i) {
+        const int per = (n_items + 7) >> 3;
+        if (i >= per) return n_items;
+        constexpr int CH = SEI_XCD_CHUNK;
+        const int full = per / CH;
+        int v;
+        if (i < full * CH) v = ((i / CH) * 8 + xcd) * CH + i % CH;
+        else v = full * CH * 8 + xcd * (per - full * CH) + (i - full * CH);
+        return v < n_items ? v : n_items;
+    };
+    int vid;
+    if constexpr (PERSIST) {
+        if (threadIdx.x == 0) *lds_ticket = atomicAdd(&work[xcd], 1);
+        __syncthreads();
+        vid = item_of(__builtin_amdgcn_readfirstlane(*lds_ticket));
+        __syncthreads();   // everybody has read the ticket before prefetch_step may overwrite it
+    } else {
+        vid = xcd_item(n_items);
+    }
+    if (vid >= n_items) return;
+    Ctx cx = ctx_finish(ctx_request(vid));
     auto cnt_of = [&](const MRound &r) { return (int)((r.ends >> (8 * (MO - 1))) & 0xFF); };
     auto last_of = [&](const MRound &r) { return (int)((r.offs >> (8 * (MO - 1))) & 0xFF); };
-    auto plan = [&](int q0, int c) {   // the round starting at sub-chunk q0; c: an offset at or below the one holding q0
+    auto plan = [&](const Ctx &cx, int q0, int c) {   // the round starting at sub-chunk q0; c: an offset at or below the one holding q0
+        const int n = cx.n;
         MRound r;
         r.q0 = q0;
         if (q0 >= n) { r.m = 0; r.offs = 0x01010101u * (uint32_t)(c < K ? c : K - 1); r.ends = 0; return r; }
-        while (seg_at(c + 1) <= q0) c = next_nonempty(c);
+        while (seg_at(cx, c + 1) <= q0) c = next_nonempty(cx, c);
         uint32_t offs = 0, ends = 0;
         int m = 0, e = 0;
         bool open = true;
 #pragma unroll
         for (int j = 0; j < MO; j++) {
             if (open) {
-                const int end = seg_at(c + 1) - q0;
+                const int end = seg_at(cx, c + 1) - q0;
                 e = end < NW ? end : NW;
                 m = j + 1;
             }
@@ -762,7 +799,7 @@ __global__ __launch_bounds__(64 * NW, 4) void conv_mround_mfma_kernel(
             if (open) {
                 if (e == NW) open = false;
                 else {
-                    const int c2 = next_nonempty(c);
+                    const int c2 = next_nonempty(cx, c);
                     if (c2 >= K) open = false; else c = c2;
                 }
             }
@@ -771,15 +808,18 @@ __global__ __launch_bounds__(64 * NW, 4) void conv_mround_mfma_kernel(
         return r;
     };
     struct Idx { int src; uint32_t d4; };
-    auto load_idx = [&](const MRound &r) {  // clamped: never branch around a load; validity is applied where it is used
+    auto load_idx = [&](const Ctx &cx, const MRound &r) {  // clamped: never branch around a load; validity is applied where it is used
         const int q = r.q0 + wave, q1 = r.q0 + cnt_of(r);
-        const int qc = q < q1 ? q : (r.q0 < n ? r.q0 : n - 1);
-        const int64_t sb = (sub0 + qc) * SUB_SLOTS;
+        const int qc = q < q1 ? q : (r.q0 < cx.n ? r.q0 : (cx.n > 0 ? cx.n - 1 : 0));
+        const int64_t sb = ((int64_t)cx.sub0 + qc) * SUB_SLOTS;
         Idx v;
         v.src = sub_src[sb + r16];
         v.d4 = *reinterpret_cast<const uint32_t *>(sub_dst + sb + 4 * g);
         return v;
     };
+    const float *Wt = W;        // this item's column block of the weights / of the bias
+    const float *biast = bias;
+    int tile = 0, ycol0 = 0;
     auto stage = [&](const MRound &r, int s, int buf) {   // slice s of every offset of round r; pieces dealt over all waves
 #ifdef SEI_ABL_NODMA   // diagnostic: the weight slices are never staged (results wrong, timing only)
         if (r.q0 >= 0) return;
@@ -793,7 +833,7 @@ __global__ __launch_bounds__(64 * NW, 4) void conv_mround_mfma_kernel(
             const int j = lin / PIECES, p = lin - j * PIECES;
             if (NB == 3 || (lin < TOT && j < r.m)) {                                  // NB == 3: always (byte j >= m repeats the last offset)
                 const int off = (r.offs >> (8 * j)) & 0xFF;
-                const float *gp = W + ((size_t)off * CIN + (size_t)s * SL) * COUT + p * 256 + lane * 4;
+                const float *gp = Wt + ((size_t)off * CIN + (size_t)s * SL) * COUT + p * 256 + lane * 4;
                 float *lp = dst + (size_t)j * SL * COUT + p * 256;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gp,
                                                  (__attribute__((address_space(3))) void *)lp, 16, 0, 0);
@@ -802,9 +842,54 @@ __global__ __launch_bounds__(64 * NW, 4) void conv_mround_mfma_kernel(
         asm volatile("" ::: "memory");   // requested BEFORE the gathers that follow (the counted waits rely on it)
     };
 
+    // PERSIST: the next item, requested step by step while this one computes (pf: steps done)
+    int pf = 0, nvid = n_items, ticket_v = 0;
+    CtxReq nq{};
+    Ctx ncx{};
+    MRound pr0{}, pr1{}, pr2{};
+    Idx pi0{}, pi1{}, pi2{};
+    auto prefetch_step = [&]() {   // wave-uniform; steps 1 and 2 are separated by a barrier (they run in different rounds)
+        if (pf == 0) {
+            if (threadIdx.x == 0) ticket_v = atomicAdd(&work[xcd], 1);
+        } else if (pf == 1) {
+            if (threadIdx.x == 0) *lds_ticket = ticket_v;
+        } else if (pf == 2) {
+            nvid = item_of(__builtin_amdgcn_readfirstlane(*lds_ticket));
+            if (nvid < n_items) nq = ctx_request(nvid);
+        } else if (pf == 3) {
+            if (nvid < n_items) {
+                ncx = ctx_finish(nq);
+                if (ncx.n > 0) {   // (a tile without rules has no sub-chunk to read an index from)
+                    pr0 = plan(ncx, 0, 0);
+                    pr1 = plan(ncx, cnt_of(pr0), last_of(pr0));
+                    pr2 = plan(ncx, pr1.q0 + cnt_of(pr1), last_of(pr1));
+                    pi0 = load_idx(ncx, pr0); pi1 = load_idx(ncx, pr1); pi2 = load_idx(ncx, pr2);
+                }
+            }
+        }
+        asm volatile("" ::: "memory");
+        pf++;
+    };
+    bool planned = false;   // r0 .. r2 / ic .. i2 of this item came with the prefetch
+    MRound r0{}, r1{}, r2{};
+    Idx ic{}, i1{}, i2{};
+  for (;;) {   // one work item per iteration (PERSIST: until the XCD's tickets are used up; else once)
+    tile = vid / blocks;
+    {
+        const int cblk = vid - tile * blocks;
+        Wt = W + (size_t)cblk * K * CIN * COUT;
+        biast = bias ? bias + cblk * COUT : nullptr;
+        ycol0 = cblk * COUT;
+    }
+    tile_init<TR, COUT, 64 * NW>(acc_tile, biast, init, (int64_t)tile * TR, n_dst, ldy, ycol0);
+    __syncthreads();
+    const int n = cx.n;
+    pf = 0;
     if (n > 0) {
-        MRound r0 = plan(0, 0), r1 = plan(cnt_of(r0), last_of(r0)), r2 = plan(r1.q0 + cnt_of(r1), last_of(r1));
-        Idx ic = load_idx(r0), i1 = load_idx(r1), i2 = load_idx(r2);
+        if (!planned) {
+            r0 = plan(cx, 0, 0); r1 = plan(cx, cnt_of(r0), last_of(r0)); r2 = plan(cx, r1.q0 + cnt_of(r1), last_of(r1));
+            ic = load_idx(cx, r0); i1 = load_idx(cx, r1); i2 = load_idx(cx, r2);
+        }
         stage(r0, 0, 0);
         if (NB == 3) stage(r0, 1, 1);
         float4 a_c[NP][1][SLJ];
@@ -872,6 +957,7 @@ __global__ __launch_bounds__(64 * NW, 4) void conv_mround_mfma_kernel(
                     MST(4);
                     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" SEI_BARRIER_INSN ::: "memory");
                     MST(0);
+                    if constexpr (PERSIST) { if (s == 0 && pf < 4) prefetch_step(); }
                     // everything requested so far has landed: tell hipcc, so that it plants no wait of its own behind the
                     // requests of THIS phase
 #pragma unroll
@@ -884,8 +970,8 @@ __global__ __launch_bounds__(64 * NW, 4) void conv_mround_mfma_kernel(
                         a_c[1 - s][0][jj] = load_a(X, s == 0 ? rowc : rown, CIN, 16 * (SLJ * (1 - s) + jj) + 4 * g);
                     asm volatile("" ::: "memory");
                     if (s == 0) {
-                        r3 = plan(r2.q0 + cnt_of(r2), last_of(r2));
-                        i3 = load_idx(r3);
+                        r3 = plan(cx, r2.q0 + cnt_of(r2), last_of(r2));
+                        i3 = load_idx(cx, r3);
                         asm volatile("" ::: "memory");
                         MST(1);
                         if (pend_g == 1) {   // group 1 of the previous round, behind this barrier (MO == 2)
@@ -919,6 +1005,7 @@ __global__ __launch_bounds__(64 * NW, 4) void conv_mround_mfma_kernel(
                     else
                         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\t" SEI_BARRIER_INSN ::"n"(KEEP) : "memory");
                     MST(0);
+                    if constexpr (PERSIST) { if (s == 0 && pf < 4) prefetch_step(); }
                     {
                         constexpr int jg = (s + 3 * NP - 3) % NP;   // the gathers of two phases ago are in (no wait of hipcc's own)
     #pragma unroll
@@ -941,8 +1028,8 @@ __global__ __launch_bounds__(64 * NW, 4) void conv_mround_mfma_kernel(
                             asm volatile("" ::: "memory");
                         }
                         if (s == IDXP) {
-                            r3 = plan(r2.q0 + cnt_of(r2), last_of(r2));
-                            i3 = load_idx(r3);
+                            r3 = plan(cx, r2.q0 + cnt_of(r2), last_of(r2));
+                            i3 = load_idx(cx, r3);
                             asm volatile("" ::: "memory");
                         }
                     };
@@ -1000,6 +1087,20 @@ __global__ __launch_bounds__(64 * NW, 4) void conv_mround_mfma_kernel(
     if (stats) tile_stats<TR, COUT, 64 * NW>(acc_tile, stats, tile, row0, n_dst, ldy, ycol0);
     MST(7);
     MST_ADD(11, 1);
+    if constexpr (!PERSIST) break;
+    // a tile of fewer than four rounds has not finished the requests for the next item: the rest runs here, exposed
+    while (pf < 4) {
+        prefetch_step();
+        __syncthreads();
+    }
+    if (nvid >= n_items) break;
+    vid = nvid;
+    planned = nvid < n_items && ncx.n > 0;
+    cx = ncx;
+    r0 = pr0; r1 = pr1; r2 = pr2;
+    ic = pi0; i1 = pi1; i2 = pi2;
+    __syncthreads();   // the store has read the tile (and every wave the ticket) before the next item initialises / overwrites them
+  }
     MST_FLUSH;
     CLK_END(1);
 }
@@ -1238,6 +1339,34 @@ static Round16 round16_plan(int nt, int nIn) {
     return {0, 0, 0, 2};
 }
 
+// PERSIST form of conv_mround_mfma_kernel (two offsets, two buffers)
+// (experiment builds, SEI_ROUND_PERSIST=1; measured and not adopted: +1.1 % at level 1, -2 ... -6 % at levels 2-4 and -23 % at level 5,
+// where the prefetched state spills 43 registers: profiles/r05_round_persistent_ab.log)
+static bool round_persist(int fam, int mo, int nb, int nIn) {
+    bool on = false;
+#ifdef SEI_EXPERIMENTS
+    if (const char *e = getenv("SEI_ROUND_PERSIST")) on = atoi(e) != 0;
+#endif
+    (void)nIn;
+    return on && fam == 3 && mo == 2 && nb == 2;
+}
+
+static int device_cu_count() {   // compute units of the current device (cached per device)
+    static std::mutex mu;
+    static std::map<int, int> cus;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cus.find(dev);
+    if (it != cus.end()) return it->second;
+    hipDeviceProp_t prop;
+    int n = 256;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n = prop.multiProcessorCount;
+    n = (n / 8) * 8 > 0 ? (n / 8) * 8 : 8;
+    cus[dev] = n;
+    return n;
+}
+
 // [r5] the 64 -> 64 plane layers of large levels (level 1 of the DUNE network) leave the wave-private kernel for the
 // sixteen-wave multi-offset rounds (conv_mround_mfma_kernel<4, 16, 4, 1, 4>)
 bool conv_rounds_64(int nIn, int nOut, int K, int64_t n_dst) {
@@ -1315,7 +1444,7 @@ static ConvPlan plan_tile(int nIn, int nOut, int K, int64_t n_dst) {
 #ifdef SEI_EXPERIMENTS
                 if (const char *e = getenv("SEI_ROUND_NW")) wide = wide && atoi(e) == 16;
 #endif
-                if (wide) { p.nw = 16; p.mo = r16p.mo; p.g = r16p.fam; p.nb = r16p.nb; p.slj = (r16p.nb * r16p.mo * r16p.slj + 1) / 2; }   // slj sizes the LDS: nb buffers of mo slices
+                if (wide) { p.nw = 16; p.mo = r16p.mo; p.g = r16p.fam; p.nb = r16p.nb; p.slj = (r16p.nb * r16p.mo * r16p.slj + 1) / 2; p.persist = round_persist(r16p.fam, r16p.mo, r16p.nb, nIn); }   // slj sizes the LDS: nb buffers of mo slices
             }
         }
 #ifdef SEI_EXPERIMENTS
@@ -1393,7 +1522,7 @@ static int launch_round(const TiledRules &t, const ConvPlan &p, const float *X, 
             SEI_TRY(ensure_max_lds((const void *)conv_mround_mfma_kernel<NT, 16, NJ_, 2, 2, 3, true>, 160 * 1024));          \
             conv_mround_mfma_kernel<NT, 16, NJ_, 2, 2, 3, true><<<((t.n_tiles * p.blocks + 7) / 8) * 8, 1024, p.lds_bytes, st>>>( \
                 X, W, bias, Y, t.tile_sub_start, t.tile_seg, t.sub_src, t.sub_dst, t.n_dst, t.K, nIn, t.n_tiles, init,     \
-                NT * 16 * p.blocks, p.blocks, stats, ep);                                                                  \
+                NT * 16 * p.blocks, p.blocks, stats, ep, nullptr);                                                         \
             SEI_LAUNCH_CHECK();                                                                                            \
             return 0;                                                                                                      \
         }
@@ -1401,12 +1530,39 @@ static int launch_round(const TiledRules &t, const ConvPlan &p, const float *X, 
         if constexpr (NT == 5) { MROUND16L(10) }
 #undef MROUND16L
 #endif
+        // PERSIST (p.persist): one workgroup per CU walks the work items of its XCD by tickets (8 counters, zeroed per launch)
+#define MROUND16P(NJ_, SLJ_)                                                                                               \
+        if (p.persist && nIn == 16 * NJ_ && p.mo == 2 && p.nb == 2 && p.slj == 2 * SLJ_) {                                 \
+            int *work = nullptr;                                                                                           \
+            SEI_TRY(pool_alloc_t(&work, 8, st));                                                                           \
+            int rc_ = 0;                                                                                                   \
+            if (hipMemsetAsync(work, 0, 8 * sizeof(int), st) != hipSuccess) { set_error("conv_forward: hipMemsetAsync failed"); rc_ = 1; } \
+            if (!rc_) rc_ = ensure_max_lds((const void *)conv_mround_mfma_kernel<NT, 16, NJ_, SLJ_, 2, 2, false, true>, 160 * 1024); \
+            if (!rc_) {                                                                                                    \
+                const int items = t.n_tiles * p.blocks, cus = device_cu_count();                                           \
+                const int grid = items < cus ? ((items + 7) / 8) * 8 : cus;                                                \
+                conv_mround_mfma_kernel<NT, 16, NJ_, SLJ_, 2, 2, false, true><<<grid, 1024, p.lds_bytes, st>>>(            \
+                    X, W, bias, Y, t.tile_sub_start, t.tile_seg, t.sub_src, t.sub_dst, t.n_dst, t.K, nIn, t.n_tiles, init, \
+                    NT * 16 * p.blocks, p.blocks, stats, ep, work);                                                        \
+                if (hipGetLastError() != hipSuccess) { set_error("conv_forward: launch failed (persistent rounds)"); rc_ = 1; } \
+            }                                                                                                              \
+            pool_free(work);                                                                                               \
+            return rc_;                                                                                                    \
+        }
+#ifdef SEI_EXPERIMENTS
+        if constexpr (NT == 4) { MROUND16P(4, 2) MROUND16P(12, 2) }
+        if constexpr (NT == 6) { MROUND16P(4, 2) }
+        if constexpr (NT == 4) { MROUND16P(6, 2) MROUND16P(8, 2) MROUND16P(10, 2) }
+        if constexpr (NT == 5) { MROUND16P(8, 2) MROUND16P(10, 2) MROUND16P(12, 2) }
+        if constexpr (NT == 6) { MROUND16P(6, 2) MROUND16P(8, 2) }
+#endif
+#undef MROUND16P
 #define MROUND16(NJ_, SLJ_, MO_, NB_)                                                                                      \
         if (nIn == 16 * NJ_ && p.mo == MO_ && p.nb == NB_ && p.slj == (NB_ * MO_ * SLJ_ + 1) / 2) {                         \
             SEI_TRY(ensure_max_lds((const void *)conv_mround_mfma_kernel<NT, 16, NJ_, SLJ_, MO_, NB_>, 160 * 1024));        \
             conv_mround_mfma_kernel<NT, 16, NJ_, SLJ_, MO_, NB_><<<((t.n_tiles * p.blocks + 7) / 8) * 8, 1024, p.lds_bytes, st>>>( \
                 X, W, bias, Y, t.tile_sub_start, t.tile_seg, t.sub_src, t.sub_dst, t.n_dst, t.K, nIn, t.n_tiles, init,     \
-                NT * 16 * p.blocks, p.blocks, stats, ep);                                                                  \
+                NT * 16 * p.blocks, p.blocks, stats, ep, nullptr);                                                         \
             SEI_LAUNCH_CHECK();                                                                                            \
             return 0;                                                                                                      \
         }
