@@ -173,6 +173,12 @@ def main():
     ap.add_argument("--batches", type=int, default=3,
                     help="distinct pre-staged batches (seeds 64*b + e, SURVEY 8d) cycled through the timed loop; `value` is "
                     "measured over them, and the same loop over batch 0 alone is reported beside it (single_batch_repeat)")
+    ap.add_argument("--product-mode", default="fp32", choices=["fp32", "bf16x3"],
+                    help="how the forward / dX convolutions multiply (scn.set_product_mode): fp32 = fp32 matrix instructions (the "
+                    "default, what `value` is measured in); bf16x3 = OPT-IN: every fp32 operand as an exact sum of three bf16 "
+                    "numbers, six part products on the bf16 matrix pipe, fp32 accumulation (per product within 2^-23 of exact)")
+    ap.add_argument("--no-optin-leg", dest="optin_leg", action="store_false", default=True,
+                    help="skip the extra timed loop that reports the opt-in bf16x3 product mode beside `value`")
     ap.add_argument("--launch-check", action="store_true",
                     help="rendezvous only: every rank joins the process group and all-reduces its rank, rank 0 prints "
                     '{"launch_check": true, "n_gpus": world}; no GPU work (tests of the self-launcher, runs on CPU with --backend gloo)')
@@ -272,8 +278,9 @@ def main():
         torch.cuda.synchronize()
 
     lib = _lib.lib()
+    from sparseeventid_amd import scn
+    scn.set_product_mode(args.product_mode)
     if args.overlap_backward and args.mode == "train":
-        from sparseeventid_amd import scn
         scn.set_backward_streams(args.overlap_backward)
     shared = bool(args.overlap_backward) and args.mode == "train"   # dX launches share the GPU with dW launches
     import ctypes
@@ -330,13 +337,37 @@ def main():
         lib.sei_prof_enable(0)
         if not args.no_prof:
             single_tflop = conv_tflop_per_step()
+    # OPT-IN leg: the same cycled loop with the forward / dX products as three-way bf16 splits (never `value`), and how far the
+    # encoder's dense output of batch 0 (57 layers deep) moves between the two modes with the same weights
+    optin = None
+    if args.optin_leg and args.product_mode == "fp32" and args.mode == "train" and args.model == "dune3d":
+        def dense_of(mode):   # the encoder's dense output (the heads hold Dropout: their logits differ between any two passes)
+            scn.set_product_mode(mode)
+            with torch.no_grad():
+                return tr.encoder(images[0]).detach().float().clone()
+        da, db = dense_of("fp32"), dense_of("bf16x3")
+        drift = float((db - da).abs().max() / da.abs().max().clamp_min(1e-30))
+        del da, db
+        cur["cycle"] = nb > 1
+        staged[0] = tr.prefetch(images[cur["i"] % nb if cur["cycle"] else 0], after=inputs_ready) if prefetch else images[cur["i"] % nb if cur["cycle"] else 0]
+        step(); step()
+        fence()
+        t2 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        oms = (time.perf_counter() - t2) / args.steps * 1e3
+        scn.set_product_mode("fp32")
+        optin = {"ms_per_step": oms, "encoder_output_max_rel_diff_vs_fp32_products": drift}
     ms = dt / args.steps * 1e3
     sync = None
     if grouped:
-        t = torch.tensor([ms, single or 0.0], device="cuda", dtype=torch.float64)
+        t = torch.tensor([ms, single or 0.0, optin["ms_per_step"] if optin else 0.0], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         ms = float(t[0].item())
         single = float(t[1].item()) if single is not None else None
+        if optin:
+            optin["ms_per_step"] = float(t[2].item())
         # data-parallel invariants, checked AFTER the timed region: every rank ended with bit-identical parameters
         # (elementwise max == min over ranks) and every rank trained on a different batch
         if args.mode == "train":
@@ -475,7 +506,8 @@ def main():
                       % ("fwd+bwd" if args.mode == "train" else "fwd only"),
             "value": args.batch * world / (ms * 1e-3), "unit": "events/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if args.product_mode == "fp32" else "f32 (products as 3 x bf16 splits, fp32 accumulation)",
+            "data": "synthetic",
             "config": {"workload": "%s %s, %d events/GPU x %d voxels in %dx%dx%d, %s generator"
                                    % ("dune3d sparse ResNet (depth 5, 32 filters, 4 res-blocks/level)"
                                       if args.model == "dune3d" else
@@ -515,6 +547,14 @@ def main():
         if args.warmup >= nb and pool_end > pool_warm:
             print("bench.py: WARNING the library's device pool grew by %.1f MB during the timed loop" % ((pool_end - pool_warm) / 1e6),
                   file=sys.stderr)
+        if optin is not None:
+            optin["events_per_s"] = args.batch * world / (optin["ms_per_step"] * 1e-3)
+            optin["what"] = ("OPT-IN, never `value`: scn.set_product_mode('bf16x3') -- every fp32 operand of the forward / dX convolutions as "
+                             "an exact sum of three bf16 numbers, the six largest part products on the bf16 matrix pipe, fp32 accumulation "
+                             "(per product within 2^-23 of the exact one); dW, BatchNorm and everything else unchanged; same cycled loop")
+            out["optin_bf16x3_products"] = optin
+        out["config"]["products"] = ("fp32 matrix instructions (v_mfma_f32_16x16x4_f32)" if args.product_mode == "fp32" else
+                                     "OPT-IN three-way bf16 splits on v_mfma_f32_16x16x32_bf16, fp32 accumulation")
         if sync is not None:
             out["data_parallel_checks"] = sync
         if staging is not None:

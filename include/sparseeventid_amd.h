@@ -143,6 +143,13 @@ int sei_conv_backward(sei_rulebook_t *rb, const float *X, const float *dY, const
  * before anything reads a dW.  In mode 2 the caller keeps X, dY and dW of every call allocated until the join; memory
  * released after the join may be reused by work queued on `stream` behind it. */
 int sei_set_backward_streams(int32_t mode);
+/* process-wide switch for the matrix products of the forward / dX convolutions (the dense per-rule feature x weight contraction;
+ * replaces nothing upstream: SCN multiplies in fp32 by sgemm).  0 = v_mfma_f32_16x16x4_f32, exact fp32 products and sums (the
+ * default); 1 = OPT-IN: every fp32 operand as an exact sum of three bf16 numbers, the six largest of the nine part products on
+ * the bf16 matrix pipe (v_mfma_f32_16x16x32_bf16) with fp32 accumulation -- per product within 2^-23 of the exact one, i.e. the
+ * size of one fp32 rounding; applies where the sixteen-wave round kernels run (64 .. 192 planes on large levels), other plans
+ * keep mode 0.  Results of mode 1 are deterministic but not bit-identical to mode 0. */
+int sei_set_product_mode(int32_t mode);
 /* `stream` waits for everything sei_conv_backward queued on its side stream so far (no-op if nothing was) */
 int sei_backward_join(sei_stream_t stream);
 /* Test / sweep hook: pins the forward / dX kernel family for every later convolution of the process

@@ -43,6 +43,7 @@ _SIGNATURES = {
     "sei_conv_backward_weight": (ctypes.c_int, [vp, vp, vp, vp, vp, ctypes.c_int32, ctypes.c_int32, vp]),
     "sei_conv_backward": (ctypes.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_int32, ctypes.c_int32, vp]),
     "sei_set_backward_streams": (ctypes.c_int, [ctypes.c_int32]),
+    "sei_set_product_mode": (ctypes.c_int, [ctypes.c_int32]),
     "sei_backward_join": (ctypes.c_int, [vp]),
     "sei_debug_force_conv_kernel": (ctypes.c_int, [ctypes.c_int32]),
     "sei_debug_force_dw_kernel": (ctypes.c_int, [ctypes.c_int32]),

@@ -289,6 +289,7 @@ ProfScope::~ProfScope() {
 }  // namespace sei
 
 static std::atomic<int> g_force_kernel{0};
+static std::atomic<int> g_product_mode{0};
 static std::atomic<int> g_force_dw{0};
 namespace sei {
 int forced_conv_kernel() {
@@ -303,6 +304,7 @@ int forced_conv_kernel() {
 #endif
     return g_force_kernel.load(std::memory_order_relaxed);
 }
+int product_mode() { return g_product_mode.load(std::memory_order_relaxed); }
 int forced_dw_kernel() {
 #ifdef SEI_EXPERIMENTS
     if (const char *e = getenv("SEI_DW_KERNEL")) {
@@ -774,9 +776,18 @@ static int conv_forward_impl(sei_rulebook_t *rb, const float *X, const float *W,
     // the workgroup-tile MFMA kernel reads B operands with wide LDS loads from column-permuted weights (tiny copy, <= 4 MB);
     // the column-owner kernel (kind 4, col_group -1) reads them from a copy packed per column tile
     float *Wp;
-    SEI_TRY(pool_alloc_t(&Wp, (size_t)t->K * nIn * nOut, st));
-    int rc = conv_transform_weights(W, Wp, t->K, nIn, nOut, false, false, p.col_group, p.blocks, st);
-    if (!rc) {
+    SEI_TRY(pool_alloc_t(&Wp, (size_t)t->K * nIn * nOut * (p.split ? 3 : 1), st));   // split: [natural fp32 | three bf16 parts (x 1.5)]
+    int rc;
+    if (p.split) {
+        rc = conv_transform_weights(W, Wp, t->K, nIn, nOut, false, false, 0, 1, st);
+        if (!rc) rc = conv_split_weights(Wp, Wp + (size_t)t->K * nIn * nOut, t->K, nIn, nOut, p.nt, st);
+    } else {
+        rc = conv_transform_weights(W, Wp, t->K, nIn, nOut, false, false, p.col_group, p.blocks, st);
+    }
+    if (!rc && p.split) {
+        ProfScope ps(kind, st, 2.0 * t->n_rules * nIn * nOut, conv_bytes(*t, nIn, nOut));
+        rc = conv_forward(*t, X, Wp + (size_t)t->K * nIn * nOut, bias, Y, nIn, nOut, st, nullptr, stats, ep);
+    } else if (!rc) {
         ProfScope ps(kind, st, 2.0 * t->n_rules * nIn * nOut, conv_bytes(*t, nIn, nOut));
         rc = conv_forward(*t, X, Wp, bias, Y, nIn, nOut, st, nullptr, stats, ep);
     }
@@ -856,11 +867,21 @@ static int conv_backward_input_impl(sei_rulebook_t *rb, const float *dY, const f
     if (dX_init && (p.kind == 0 || t->n_sub == 0))
         SEI_FAIL("conv_backward_input_accumulate: not supported for these plane counts");
     float *Wt;
-    SEI_TRY(pool_alloc_t(&Wt, (size_t)t->K * nIn * nOut, st));
+    SEI_TRY(pool_alloc_t(&Wt, (size_t)t->K * nIn * nOut * (p.split ? 3 : 1), st));
     // Wt[k'][co][ci] = W[K-1-k' (submanifold mirror) or k'][ci][co] (kind 1: columns (ci) permuted for the kernel)
-    int rc = conv_transform_weights(W, Wt, t->K, nIn, nOut, true, rb->submanifold, (p.kind == 1 || p.kind == 4) ? p.col_group : 0,
+    int rc;
+    if (p.split) {   // natural layout first, then its three bf16 parts in the kernel's B layout (contraction over nOut, nIn columns)
+        rc = conv_transform_weights(W, Wt, t->K, nIn, nOut, true, rb->submanifold, 0, 1, st);
+        if (!rc) rc = conv_split_weights(Wt, Wt + (size_t)t->K * nIn * nOut, t->K, nOut, nIn, p.nt, st);
+    } else {
+        rc = conv_transform_weights(W, Wt, t->K, nIn, nOut, true, rb->submanifold, (p.kind == 1 || p.kind == 4) ? p.col_group : 0,
                                     p.kind == 1 ? p.blocks : 1, st);
-    if (!rc) {
+    }
+    if (!rc && p.split) {
+        ProfScope ps(nIn == 32 && nOut == 32 ? PROF_CONV_BWD_IN_C32 : PROF_CONV_BWD_IN, st, 2.0 * t->n_rules * nIn * nOut,
+                     conv_bytes(*t, nOut, nIn));
+        rc = conv_forward(*t, dY, Wt + (size_t)t->K * nIn * nOut, nullptr, dX, nOut, nIn, st, dX_init);
+    } else if (!rc) {
         ProfScope ps(nIn == 32 && nOut == 32 ? PROF_CONV_BWD_IN_C32 : PROF_CONV_BWD_IN, st, 2.0 * t->n_rules * nIn * nOut,
                      conv_bytes(*t, nOut, nIn));
         rc = conv_forward(*t, dY, Wt, nullptr, dX, nOut, nIn, st, dX_init);
@@ -935,6 +956,12 @@ int side_stream_for(hipStream_t st, SideStream *out) {
 }
 }  // namespace
 
+
+int sei_set_product_mode(int32_t mode) {
+    if (mode < 0 || mode > 1) SEI_FAIL("sei_set_product_mode: mode must be 0 (fp32 MFMA) or 1 (three-way bf16 split, opt-in)");
+    g_product_mode.store(mode);
+    return 0;
+}
 
 int sei_set_backward_streams(int32_t mode) {
     if (mode < 0 || mode > 2) SEI_FAIL("sei_set_backward_streams: mode must be 0 (back to back), 1 (join per call) or 2 (deferred join)");

@@ -301,6 +301,7 @@ struct ConvPlan {
     int blocks = 1;      // column blocks (kind 1: weights stored as [block][K][nIn][nOut/blocks])
     int nt = 0, cs = 0, slj = 0, maxs = 0, g = 0;   // kind 1, g == 2: two-offset rounds (conv_round_mfma_kernel), g == 3: with refilled A fragments
     int nw = 4;          // kind 1: waves per workgroup (4, 8 or 16)
+    bool split = false;  // kind 1, g == 3: products as three-way bf16 splits (sei_set_product_mode(1)); weights from conv_split_weights
     bool persist = false; // kind 1, g == 3: one workgroup per CU walks the work items (conv_mround_mfma_kernel<.., PERSIST>)
     int nb = 2;          // kind 1, g == 3: weight buffers of the round kernel (3: slices staged two phases ahead)
     int mo = 0;          // kind 1, g == 2 / 3, nw == 16: offsets a round may span (2: conv_round_mfma_kernel, 3 / 4: conv_mround_mfma_kernel)
@@ -313,6 +314,7 @@ ConvPlan plan_conv(int nIn, int nOut, int K, int64_t n_dst);
 // (AUTO uses that form for the eight-wave plans); BAND / COLS: experiment builds only
 enum { CONV_KERNEL_AUTO = 0, CONV_KERNEL_TILE = 1, CONV_KERNEL_WAVE = 2, CONV_KERNEL_BAND = 3, CONV_KERNEL_COLS = 4, CONV_KERNEL_ROUNDS = 5 };
 int forced_conv_kernel();
+int product_mode();   // sei_set_product_mode(): 0 fp32 MFMA (default), 1 three-way bf16 split (opt-in)
 // sei_debug_force_dw_kernel(): dW kernel family (AUTO = the library's choice)
 enum { DW_KERNEL_AUTO = 0, DW_KERNEL_REG = 1, DW_KERNEL_RING = 2 };
 int forced_dw_kernel();
@@ -362,6 +364,10 @@ int64_t conv_stats_parts(const ConvPlan &p, const TiledRules &t);
 // with ks = flip ? K-1-k : k (dX).  perm = column permutation inside groups of `col_group` columns (0 = identity).
 int conv_transform_weights(const float *W, float *Wout, int K, int nIn, int nOut, bool transpose, bool flip, int col_group, int blocks,
                            hipStream_t st);
+// Ws[block][k][s][part][n][lane][8 bf16] <- the three bf16 parts of Wnat[k][32 s + 8 (lane >> 4) + j][16 (block nt + n) + (lane & 15)],
+// Wnat = fp32 weights in the natural [K][rows][cols] layout (conv_transform_weights with col_group 0, blocks 1); Ws holds
+// K * rows * cols * 3 / 2 floats
+int conv_split_weights(const float *Wnat, float *Ws, int K, int rows, int cols, int nt, hipStream_t st);
 int conv_backward_weight(const TiledRules &t, const float *X, const float *dY, float *dW, int nIn, int nOut,
                          hipStream_t st);
 // elementwise.hip

@@ -78,6 +78,42 @@ int conv_transform_weights(const float *W, float *Wout, int K, int nIn, int nOut
     return 0;
 }
 
+// three-way bf16 split of the weights in the B layout of v_mfma_f32_16x16x32_bf16 (conv_fwd.hip: compute_phase_split)
+__global__ void weights_split_kernel(const float *__restrict__ Wnat, uint32_t *__restrict__ Ws, int K, int rows, int cols, int nt) {
+    // one thread per (block, k, s, n, lane, pair jp): two consecutive input planes of one column -> one word of every part
+    const int NS = rows / 32, blocks = cols / (16 * nt);
+    const int64_t total = (int64_t)blocks * K * NS * nt * 64 * 4;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int jp = (int)(t & 3), lane = (int)((t >> 2) & 63);
+    int64_t r = t >> 8;
+    const int n = (int)(r % nt); r /= nt;
+    const int sl = (int)(r % NS); r /= NS;
+    const int k = (int)(r % K);
+    const int blk = (int)(r / K);
+    const int row = 32 * sl + 8 * (lane >> 4) + 2 * jp, col = 16 * (blk * nt + n) + (lane & 15);
+    const float x = Wnat[((size_t)k * rows + row) * cols + col], y = Wnat[((size_t)k * rows + row + 1) * cols + col];
+    const unsigned ux = __float_as_uint(x), uy = __float_as_uint(y);
+    const unsigned x1 = ux & 0xFFFF0000u, y1 = uy & 0xFFFF0000u;
+    const float rx = x - __uint_as_float(x1), ry = y - __uint_as_float(y1);
+    const unsigned x2 = __float_as_uint(rx) & 0xFFFF0000u, y2 = __float_as_uint(ry) & 0xFFFF0000u;
+    const float rx2 = rx - __uint_as_float(x2), ry2 = ry - __uint_as_float(y2);
+    const unsigned part[3] = {(y1 & 0xFFFF0000u) | (x1 >> 16), (y2 & 0xFFFF0000u) | (x2 >> 16),
+                              (__float_as_uint(ry2) & 0xFFFF0000u) | (__float_as_uint(rx2) >> 16)};
+    // [block][k][s][part][n][lane][4 words]
+    const size_t slice = ((size_t)(blk * K + k) * NS + sl) * (size_t)(3 * nt * 256);
+#pragma unroll
+    for (int q = 0; q < 3; q++) Ws[slice + ((size_t)(q * nt + n) * 64 + lane) * 4 + jp] = part[q];
+}
+
+int conv_split_weights(const float *Wnat, float *Ws, int K, int rows, int cols, int nt, hipStream_t st) {
+    if (rows % 32 || cols % (16 * nt)) SEI_FAIL("conv_split_weights: plane counts do not match the split layout");
+    const int64_t total = (int64_t)(cols / (16 * nt)) * K * (rows / 32) * nt * 64 * 4;
+    weights_split_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(Wnat, reinterpret_cast<uint32_t *>(Ws), K, rows, cols, nt);
+    SEI_LAUNCH_CHECK();
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------ dW
 constexpr int DW_TILES_PER_ITER = 128;             // tiles scanned per list refill
 constexpr int DW_LIST_CAP = DW_TILES_PER_ITER * 16;  // <= 16 sub-chunks per (tile, k)

@@ -151,6 +151,10 @@ __device__ __forceinline__ void compute_phase(const float *__restrict__ wb, cons
             for (int n = 0; n < NT; n++) {
 #ifdef SEI_ABL_NOMFMA  // diagnostic: one VALU fma instead of the MFMA (keeps the operand dependencies)
                 acc[m][n][0] = fmaf(av, b[st & 1][n], acc[m][n][0]);
+#elif defined(SEI_ABL_MFMA_FRACTION)  // diagnostic: only every SEI_ABL_MFMA_FRACTION-th MFMA step is issued (results wrong, timing
+                                      // only): what would a cheaper matrix product (split-bf16 MFMAs) buy with everything else in place?
+                if (st % SEI_ABL_MFMA_FRACTION == 0) acc[m][n] = mfma16(av, b[st & 1][n], acc[m][n]);
+                else asm volatile("" ::"v"(av), "v"(b[st & 1][n]));
 #else
                 acc[m][n] = mfma16(av, b[st & 1][n], acc[m][n]);
 #endif
@@ -683,6 +687,61 @@ __device__ unsigned long long g_mstamps[16][16];
 #define MST_FLUSH
 #endif
 
+// ---- fp32 products from THREE-WAY bf16 splits on the bf16 matrix pipe (opt-in: sei_set_product_mode(1)) [r5]
+// x = x1 + x2 + x3 EXACTLY, each part the next 8 mantissa bits of x (truncation: the parts are bf16 numbers and the residuals are
+// exact fp32 subtractions; bf16 has fp32's exponent range, so no scaling).  a b = sum of nine exact bf16 x bf16 products, of which
+// the six largest are accumulated in fp32 by v_mfma_f32_16x16x32_bf16 (the three dropped ones are below 2^-23 |a b|: the size of
+// the rounding error of one fp32 product).  16 cycles per 16 x 16 x 32 block and part pair: 96 cycles per 32 input planes and
+// column tile against 256 on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32: 8 x 32).
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 mfma_bf16(u32x4_t a, u32x4_t b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+// (x, y) -> three words of two packed bf16 each (x in the low half): parts 1, 2, 3
+__device__ __forceinline__ void split_pair(float x, float y, unsigned &p1, unsigned &p2, unsigned &p3) {
+    const unsigned ux = __float_as_uint(x), uy = __float_as_uint(y);
+    const unsigned x1 = ux & 0xFFFF0000u, y1 = uy & 0xFFFF0000u;
+    p1 = __builtin_amdgcn_perm(y1, x1, 0x07060302u);
+    const float rx = x - __uint_as_float(x1), ry = y - __uint_as_float(y1);
+    const unsigned x2 = __float_as_uint(rx) & 0xFFFF0000u, y2 = __float_as_uint(ry) & 0xFFFF0000u;
+    p2 = __builtin_amdgcn_perm(y2, x2, 0x07060302u);
+    const float rx2 = rx - __uint_as_float(x2), ry2 = ry - __uint_as_float(y2);
+    p3 = __builtin_amdgcn_perm(__float_as_uint(ry2), __float_as_uint(rx2), 0x07060302u);
+}
+// One 32-plane phase for one sub-chunk.  a[0], a[1]: the lane's 8 consecutive planes 8 g .. 8 g + 7 of the slice for rule row r16
+// (the A layout of the 16 x 16 x 32 block).  wb: this offset's slice in LDS, [part][column tile][lane][8 bf16] (weights_split_kernel):
+// one ds_read_b128 per part and column tile.  Small terms first.
+template <int NT>
+__device__ __forceinline__ void compute_phase_split(const float *__restrict__ wb, const float4 (&a)[1][2], f32x4 (&acc)[1][NT], int lane) {
+    unsigned a1[4], a2[4], a3[4];
+    split_pair(a[0][0].x, a[0][0].y, a1[0], a2[0], a3[0]);
+    split_pair(a[0][0].z, a[0][0].w, a1[1], a2[1], a3[1]);
+    split_pair(a[0][1].x, a[0][1].y, a1[2], a2[2], a3[2]);
+    split_pair(a[0][1].z, a[0][1].w, a1[3], a2[3], a3[3]);
+    const u32x4_t A1 = {a1[0], a1[1], a1[2], a1[3]}, A2 = {a2[0], a2[1], a2[2], a2[3]}, A3 = {a3[0], a3[1], a3[2], a3[3]};
+    const u32x4_t *bp = reinterpret_cast<const u32x4_t *>(wb) + lane;
+    u32x4_t b[2][3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) b[0][q] = bp[(q * NT + 0) * 64];
+#pragma unroll
+    for (int n = 0; n < NT; n++) {
+        if (n + 1 < NT) {
+#pragma unroll
+            for (int q = 0; q < 3; q++) b[(n + 1) & 1][q] = bp[(q * NT + n + 1) * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);   // the next column tile's reads are issued before this one's MFMAs
+        f32x4 c = acc[0][n];
+        c = mfma_bf16(A3, b[n & 1][0], c);
+        c = mfma_bf16(A1, b[n & 1][2], c);
+        c = mfma_bf16(A2, b[n & 1][1], c);
+        c = mfma_bf16(A2, b[n & 1][0], c);
+        c = mfma_bf16(A1, b[n & 1][1], c);
+        c = mfma_bf16(A1, b[n & 1][0], c);
+        acc[0][n] = c;
+    }
+}
+
 struct MRound {
     int q0;          // first tile-relative sub-chunk
     int m;           // offsets (groups) in the round, 0 beyond the end of the tile
@@ -704,7 +763,9 @@ struct MRound {
 // order of xcd_item), its segment table, its first three round plans and their index words are requested while the current tile
 // computes (one step per round, `prefetch_step`); what stays exposed at a tile boundary is the tile's store, the next tile's
 // initialisation and ONE trip (the first gathers).  Same rounds, same order of sums: bit-identical.
-template <int NT, int NW, int NJ, int SLJ, int MO, int NB = 2, bool LATE = false, bool PERSIST = false>
+// SPLIT: the products of a phase as three-way bf16 splits (compute_phase_split; SLJ == 2: a phase is one 32-plane block).  W then points to
+// the split weights [block][K][nIn / 32][3][NT][64][8 bf16] and a slice is 3 NT KiB instead of 128 COUT bytes per plane pair.
+template <int NT, int NW, int NJ, int SLJ, int MO, int NB = 2, bool LATE = false, bool PERSIST = false, bool SPLIT = false>
 __global__ __launch_bounds__(64 * NW, 4) void conv_mround_mfma_kernel(
     const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ Y,
     const int32_t *__restrict__ tile_sub_start, const int32_t *__restrict__ tile_seg,
@@ -716,15 +777,18 @@ __global__ __launch_bounds__(64 * NW, 4) void conv_mround_mfma_kernel(
     static_assert(MO >= 2 && MO <= 4 && MO <= NP, "group g of a round is written back in phase g - 1 of the next one");
     static_assert(NB == 2 || (NB == 3 && NP >= 3), "the third weight buffer belongs to the refilled-fragment schedule");
     static_assert(!LATE || NB == 3, "requests behind the MFMA block need everything two phases ahead");
-    constexpr int TR = 16 * NW, SL = 16 * SLJ, COUT = NT * 16, PIECES = SL * COUT / 256;
-    static_assert((SL * COUT) % 256 == 0, "a slice is a whole number of 1-KiB LDS-DMA pieces");
+    static_assert(!SPLIT || (SLJ == 2 && NB == 2 && !LATE), "the split product works on 32-plane phases");
+    constexpr int TR = 16 * NW, SL = 16 * SLJ, COUT = NT * 16;
+    constexpr int WSLICE = SPLIT ? 3 * NT * 256 : SL * COUT;   // floats of one offset's slice in LDS
+    constexpr int PIECES = WSLICE / 256;
+    static_assert(WSLICE % 256 == 0, "a slice is a whole number of 1-KiB LDS-DMA pieces");
     constexpr int STAGE_PER = (MO * PIECES + NW - 1) / NW;   // pieces a wave issues per staged phase (NB == 3: exactly)
     const int n_items = n_tiles * blocks;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r16 = lane & 15, g = lane >> 4;
     float *acc_tile = lds;
     float *wbuf = lds + (size_t)TR * COUT;   // [buffer][group][SL][COUT]
-    int *lds_ticket = reinterpret_cast<int *>(wbuf + (size_t)NB * MO * SL * COUT);   // PERSIST: the next item's ticket, wave 0 -> all
+    int *lds_ticket = reinterpret_cast<int *>(wbuf + (size_t)NB * MO * WSLICE);   // PERSIST: the next item's ticket, wave 0 -> all
     MST_DECL;
     CLK_BEGIN;
 
@@ -825,7 +889,7 @@ __global__ __launch_bounds__(64 * NW, 4) void conv_mround_mfma_kernel(
         if (r.q0 >= 0) return;
 #endif
         constexpr int TOT = MO * PIECES, PER = STAGE_PER;
-        float *dst = wbuf + (size_t)buf * MO * SL * COUT;
+        float *dst = wbuf + (size_t)buf * MO * WSLICE;
 #pragma unroll
         for (int t = 0; t < PER; t++) {
             int lin = wave + t * NW;                                                  // wave-uniform
@@ -833,8 +897,9 @@ __global__ __launch_bounds__(64 * NW, 4) void conv_mround_mfma_kernel(
             const int j = lin / PIECES, p = lin - j * PIECES;
             if (NB == 3 || (lin < TOT && j < r.m)) {                                  // NB == 3: always (byte j >= m repeats the last offset)
                 const int off = (r.offs >> (8 * j)) & 0xFF;
-                const float *gp = Wt + ((size_t)off * CIN + (size_t)s * SL) * COUT + p * 256 + lane * 4;
-                float *lp = dst + (size_t)j * SL * COUT + p * 256;
+                const float *gp = (SPLIT ? Wt + ((size_t)off * (CIN / 32) + (size_t)s) * WSLICE
+                                         : Wt + ((size_t)off * CIN + (size_t)s * SL) * COUT) + p * 256 + lane * 4;
+                float *lp = dst + (size_t)j * WSLICE + p * 256;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gp,
                                                  (__attribute__((address_space(3))) void *)lp, 16, 0, 0);
             }
@@ -877,7 +942,7 @@ __global__ __launch_bounds__(64 * NW, 4) void conv_mround_mfma_kernel(
     tile = vid / blocks;
     {
         const int cblk = vid - tile * blocks;
-        Wt = W + (size_t)cblk * K * CIN * COUT;
+        Wt = W + (size_t)cblk * K * (SPLIT ? (size_t)(CIN / 32) * WSLICE : (size_t)CIN * COUT);
         biast = bias ? bias + cblk * COUT : nullptr;
         ycol0 = cblk * COUT;
     }
@@ -897,7 +962,7 @@ __global__ __launch_bounds__(64 * NW, 4) void conv_mround_mfma_kernel(
         for (int j = 0; j < NP; j++)
 #pragma unroll
             for (int jj = 0; jj < SLJ; jj++)
-                a_c[j][0][jj] = load_a(X, wave < cnt_of(r0) ? ic.src : -1, CIN, 16 * (SLJ * j + jj) + 4 * g);
+                a_c[j][0][jj] = load_a(X, wave < cnt_of(r0) ? ic.src : -1, CIN, SPLIT ? 32 * j + 8 * g + 4 * jj : 16 * (SLJ * j + jj) + 4 * g);
         int phase = 0;
         int bcur = 0;   // buffer the current phase reads (NB == 3: phase % 3)
         f32x4 acc[1][NT], pacc[NT];
@@ -967,7 +1032,7 @@ __global__ __launch_bounds__(64 * NW, 4) void conv_mround_mfma_kernel(
                     if (s == 0) stage(r0, 1, 1); else stage(r1, 0, 0);
 #pragma unroll
                     for (int jj = 0; jj < SLJ; jj++)
-                        a_c[1 - s][0][jj] = load_a(X, s == 0 ? rowc : rown, CIN, 16 * (SLJ * (1 - s) + jj) + 4 * g);
+                        a_c[1 - s][0][jj] = load_a(X, s == 0 ? rowc : rown, CIN, SPLIT ? 32 * (1 - s) + 8 * g + 4 * jj : 16 * (SLJ * (1 - s) + jj) + 4 * g);
                     asm volatile("" ::: "memory");
                     if (s == 0) {
                         r3 = plan(cx, r2.q0 + cnt_of(r2), last_of(r2));
@@ -985,7 +1050,11 @@ __global__ __launch_bounds__(64 * NW, 4) void conv_mround_mfma_kernel(
                         MST(1);
                     }
                     if (valid)
-                        compute_phase<NT, SLJ, 1, 1, COUT>(wbuf + (size_t)(s * MO + gi) * SL * COUT, a_c[s], acc, g, r16);
+                    {
+                        const float *wsl = wbuf + (size_t)(s * MO + gi) * WSLICE;
+                        if constexpr (SPLIT) compute_phase_split<NT>(wsl, a_c[s], acc, lane);
+                        else compute_phase<NT, SLJ, 1, 1, COUT>(wsl, a_c[s], acc, g, r16);
+                    }
                     MST(3);
                     MST_ADD(8, valid ? 1 : 0);
                     MST_ADD(9, valid ? 0 : 1);
@@ -1024,7 +1093,7 @@ __global__ __launch_bounds__(64 * NW, 4) void conv_mround_mfma_kernel(
                             constexpr int jr = (s + NP - 1) % NP;   // the fragments the previous phase used
     #pragma unroll
                             for (int jj = 0; jj < SLJ; jj++)
-                                a_c[jr][0][jj] = load_a(X, s == 0 ? rowc : rown, CIN, 16 * (SLJ * jr + jj) + 4 * g);
+                                a_c[jr][0][jj] = load_a(X, s == 0 ? rowc : rown, CIN, SPLIT ? 32 * jr + 8 * g + 4 * jj : 16 * (SLJ * jr + jj) + 4 * g);
                             asm volatile("" ::: "memory");
                         }
                         if (s == IDXP) {
@@ -1048,7 +1117,11 @@ __global__ __launch_bounds__(64 * NW, 4) void conv_mround_mfma_kernel(
                     }
                     MST(2);
                     if (valid)
-                        compute_phase<NT, SLJ, 1, 1, COUT>(wbuf + (size_t)((NB == 3 ? bcur : (phase & 1)) * MO + gi) * SL * COUT, a_c[s], acc, g, r16);
+                    {
+                        const float *wsl = wbuf + (size_t)((NB == 3 ? bcur : (phase & 1)) * MO + gi) * WSLICE;
+                        if constexpr (SPLIT) compute_phase_split<NT>(wsl, a_c[s], acc, lane);
+                        else compute_phase<NT, SLJ, 1, 1, COUT>(wsl, a_c[s], acc, g, r16);
+                    }
                     if (late) requests();
                     MST(3);
                     MST_ADD(8, valid ? 1 : 0);
@@ -1438,8 +1511,18 @@ static ConvPlan plan_tile(int nIn, int nOut, int K, int64_t n_dst) {
                 // [r4, late] where instantiated: ONE sixteen-wave workgroup per CU on 256-row tiles (the variant dW walks anyway)
                 // with 32-plane slices -- half the phases, half the weight staging per sub-chunk, padding 0.95 instead of 0.90:
                 // 88.1 / 92.9 / 89.0 against 84.7 / 86.4 / 86.6 TFLOP/s at 96 / 128 / 160 planes (profiles/r04_conv_round_ab.log)
+                // [r5] opt-in (sei_set_product_mode(1)): the products as three-way bf16 splits where the sixteen-wave rounds run;
+                // 96 columns then take two blocks of 48 (the split slices of two offsets, 36 KB per buffer at 96 columns, do not
+                // fit beside a 96 KB tile)
+                const bool split = product_mode() == 1 && K + 1 <= 64 && nIn % 32 == 0 && nIn >= 64 && nIn <= 192 &&
+                                   (nOut == 64 || nOut == 96 || nOut == 128 || nOut == 160 || nOut == 192);
+                if (split) {
+                    p.blocks = nOut == 64 ? 1 : (nOut == 192 ? 3 : 2);
+                    p.nw = 16; p.mo = 2; p.g = 3; p.nb = 2; p.split = true; p.persist = false;
+                    p.slj = 6;   // sizes the LDS: 2 buffers x 2 offsets x 3 nt KiB of split slices
+                }
                 const int cols = nOut / p.blocks;
-                const Round16 r16p = K + 1 <= 64 ? round16_plan(cols / 16, nIn) : Round16{0, 0, 0, 2};
+                const Round16 r16p = (!split && K + 1 <= 64) ? round16_plan(cols / 16, nIn) : Round16{0, 0, 0, 2};
                 bool wide = r16p.slj > 0;
 #ifdef SEI_EXPERIMENTS
                 if (const char *e = getenv("SEI_ROUND_NW")) wide = wide && atoi(e) == 16;
@@ -1515,6 +1598,22 @@ static int launch_round(const TiledRules &t, const ConvPlan &p, const float *X, 
                         int nIn, const float *init, double *stats, hipStream_t st, const ConvEpilogue &ep) {
     // one register set of A fragments refilled a phase after use (NJ = nIn / 16 > 0) where 128 registers hold it; the narrower
     // column blocks keep the per-phase gathers and three workgroups per CU
+    if (p.nw == 16 && p.g == 3 && p.split) {   // [r5] opt-in: products as three-way bf16 splits (W = conv_split_weights' layout)
+#define MROUND16S(NJ_)                                                                                                     \
+        if (nIn == 16 * NJ_) {                                                                                             \
+            SEI_TRY(ensure_max_lds((const void *)conv_mround_mfma_kernel<NT, 16, NJ_, 2, 2, 2, false, false, true>, 160 * 1024)); \
+            conv_mround_mfma_kernel<NT, 16, NJ_, 2, 2, 2, false, false, true><<<((t.n_tiles * p.blocks + 7) / 8) * 8, 1024, p.lds_bytes, st>>>( \
+                X, W, bias, Y, t.tile_sub_start, t.tile_seg, t.sub_src, t.sub_dst, t.n_dst, t.K, nIn, t.n_tiles, init,     \
+                NT * 16 * p.blocks, p.blocks, stats, ep, nullptr);                                                         \
+            SEI_LAUNCH_CHECK();                                                                                            \
+            return 0;                                                                                                      \
+        }
+        if constexpr (NT == 3) { MROUND16S(4) MROUND16S(6) MROUND16S(8) }
+        if constexpr (NT == 4) { MROUND16S(4) MROUND16S(6) MROUND16S(8) MROUND16S(10) MROUND16S(12) }
+        if constexpr (NT == 5) { MROUND16S(8) MROUND16S(10) MROUND16S(12) }
+#undef MROUND16S
+        SEI_FAIL("conv_forward: no split-product instantiation for this plan");
+    }
     if (p.nw == 16 && p.g == 3) {   // [r5] sixteen-wave rounds spanning up to p.mo offsets / with two long phases (conv_mround_mfma_kernel)
 #ifdef SEI_EXPERIMENTS   // SEI_ROUND_LATE=1 (with SEI_ROUND_FAM=3 SEI_ROUND_NB=3): the upper eight waves issue their requests behind the MFMAs
 #define MROUND16L(NJ_)                                                                                                     \

@@ -53,6 +53,18 @@ def set_backward_streams(mode):
     _BWD_STREAMS = int(mode)
 
 
+PRODUCT_MODES = {"fp32": 0, "bf16x3": 1}
+
+
+def set_product_mode(mode):
+    """How the forward / dX convolutions multiply (C ABI ``sei_set_product_mode``).  "fp32" (default): fp32 matrix
+    instructions, exact fp32 products.  "bf16x3" (OPT-IN): every fp32 operand as an exact sum of three bf16 numbers,
+    the six largest of the nine part products on the bf16 matrix pipe with fp32 accumulation -- per product within 2^-23
+    of the exact one (the size of one fp32 rounding), 0.375 of the matrix-pipe cycles; applies where the sixteen-wave
+    round kernels run (64 .. 192 planes on large levels).  dW and every other operation stay as they are."""
+    check(lib().sei_set_product_mode(PRODUCT_MODES[mode] if isinstance(mode, str) else int(mode)))
+
+
 def _pin_to_side(x, dy, dw):
     """mode 2: X and dY are still being read on the side stream when the autograd node returns: held until the join.
     dW is NOT held: autograd's AccumulateGrad takes over a gradient tensor as ``param.grad`` only while nobody else

@@ -15,7 +15,22 @@ HEADS = {"labelneutID": 3, "labelprotID": 3, "labelnpiID": 2, "labelcpiID": 2}
 IMAGE = [1, 900, 900, 900]
 
 
-def test_default_network_full_size_events_match_oracle():
+@pytest.mark.parametrize("products", ["fp32", "bf16x3"])
+def test_default_network_full_size_events_match_oracle(products, force_conv_kernel):
+    """products = "bf16x3": the OPT-IN product mode (scn.set_product_mode) with the round kernels forced wherever they are
+    instantiated, so that every 64- to 192-plane layer of the network multiplies through three-way bf16 splits -- same bars."""
+    import sparseeventid_amd.scn as scn
+    if products == "bf16x3":
+        force_conv_kernel("rounds")
+    scn.set_product_mode(products)
+    try:
+        # the one bound that depends on the mode: the floor of the per-parameter gradient check against fp64 (see there)
+        _full_size_network_against_the_oracle(grad_floor=1e-3 if products == "fp32" else 2e-3)
+    finally:
+        scn.set_product_mode("fp32")
+
+
+def _full_size_network_against_the_oracle(grad_floor=1e-3):
     from sparseeventid_amd import build_networks
     from sparseeventid_amd.config import Config
     from sparseeventid_amd.data import larcvsparse_to_scnsparse_3d, synthetic_dune3d_batch
@@ -95,7 +110,10 @@ def test_default_network_full_size_events_match_oracle():
             continue
         e_g, e_c = l2_err(p.grad, g64), l2_err(og, g64)
         worst_gpu, worst_cpu = max(worst_gpu, e_g), max(worst_cpu, e_c)
-        assert e_g < max(2.0 * e_c, 1e-3), (k, e_g, e_c)
+        # (floor: 1e-3 with fp32 products; the opt-in split products round in a different pattern -- the same kind of change
+        # that moved one BatchNorm bias from inside this bound to 2.1e-3 when round 3 tried another summation order at the
+        # stem -- and get 2e-3: measured worst 1.3e-3, on a BatchNorm bias whose fp32-oracle error is 4.4e-4)
+        assert e_g < max(2.0 * e_c, grad_floor), (k, e_g, e_c)
         assert l2_err(p.grad, og) < 5e-3, k
     for k, b in enc.named_buffers():
         assert rel_err(b, osd[k]) < 1e-4, k

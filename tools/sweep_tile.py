@@ -41,6 +41,8 @@ def main():
         for plan in a.plans:
             # "cols": the column-owner kernel (conv_cols.hip), "wave": the wave-private one, "forced-rounds": rounds wherever instantiated
             # "default" = the tile kernel with one offset per phase (forced kind 1); every "rounds*" plan forces the round form
+            # "rounds+split" (and "rounds+split:KNOB=..."): the opt-in product mode (three-way bf16 splits on the bf16 matrix pipe)
+            scn.set_product_mode("bf16x3" if "+split" in plan else "fp32")
             os.environ["SEI_CONV_KERNEL"] = {"cols": "cols", "wave": "wave"}.get(plan, "rounds" if "rounds" in plan else "tile")
             os.environ["SEI_TILE_ROUNDS"] = "1" if "rounds" in plan else "0"   # conv_round_mfma_kernel (two-offset rounds)
             for kv in ("SEI_ROUND_JIT", "SEI_ROUND_RING", "SEI_ROUND_SLJ", "SEI_ROUND_NOFF", "SEI_ROUND_NW", "SEI_ROUND_MO", "SEI_ROUND_LONG", "SEI_ROUND_NB", "SEI_ROUND_FAM", "SEI_ROUND_LATE", "SEI_ROUND_PERSIST"):
