@@ -712,7 +712,7 @@ __device__ __forceinline__ void split_pair(float x, float y, unsigned &p1, unsig
 // One 32-plane phase for one sub-chunk.  a[0], a[1]: the lane's 8 consecutive planes 8 g .. 8 g + 7 of the slice for rule row r16
 // (the A layout of the 16 x 16 x 32 block).  wb: this offset's slice in LDS, [part][column tile][lane][8 bf16] (weights_split_kernel):
 // one ds_read_b128 per part and column tile.  Small terms first.
-template <int NT>
+template <int NT, int BB>
 __device__ __forceinline__ void compute_phase_split(const float *__restrict__ wb, const float4 (&a)[1][2], f32x4 (&acc)[1][NT], int lane) {
     unsigned a1[4], a2[4], a3[4];
     split_pair(a[0][0].x, a[0][0].y, a1[0], a2[0], a3[0]);
@@ -721,24 +721,33 @@ __device__ __forceinline__ void compute_phase_split(const float *__restrict__ wb
     split_pair(a[0][1].z, a[0][1].w, a1[3], a2[3], a3[3]);
     const u32x4_t A1 = {a1[0], a1[1], a1[2], a1[3]}, A2 = {a2[0], a2[1], a2[2], a2[3]}, A3 = {a3[0], a3[1], a3[2], a3[3]};
     const u32x4_t *bp = reinterpret_cast<const u32x4_t *>(wb) + lane;
-    u32x4_t b[2][3];
+    // BB == 2: the B parts of the NEXT column tile are read while this one multiplies (24 registers); BB == 1: the reads of a column
+    // tile sit behind the previous tile's MFMAs (12 registers) -- at 192 input planes, where the fragments of a whole row leave no
+    // room (15 registers spilled with two sets: 110 against 122 fp32-equivalent TFLOP/s at level 5; at 64 / 128 planes two sets
+    // are 3-4 % faster: profiles/r05_split_products_ab.log)
+    u32x4_t b[BB][3];
 #pragma unroll
     for (int q = 0; q < 3; q++) b[0][q] = bp[(q * NT + 0) * 64];
 #pragma unroll
     for (int n = 0; n < NT; n++) {
-        if (n + 1 < NT) {
+        if (BB == 2 && n + 1 < NT) {
 #pragma unroll
             for (int q = 0; q < 3; q++) b[(n + 1) & 1][q] = bp[(q * NT + n + 1) * 64];
         }
-        __builtin_amdgcn_sched_barrier(0);   // the next column tile's reads are issued before this one's MFMAs
+        if (BB == 2) __builtin_amdgcn_sched_barrier(0);   // the next column tile's reads are issued before this one's MFMAs
+        const int cb = BB == 2 ? (n & 1) : 0;
         f32x4 c = acc[0][n];
-        c = mfma_bf16(A3, b[n & 1][0], c);
-        c = mfma_bf16(A1, b[n & 1][2], c);
-        c = mfma_bf16(A2, b[n & 1][1], c);
-        c = mfma_bf16(A2, b[n & 1][0], c);
-        c = mfma_bf16(A1, b[n & 1][1], c);
-        c = mfma_bf16(A1, b[n & 1][0], c);
+        c = mfma_bf16(A3, b[cb][0], c);
+        c = mfma_bf16(A1, b[cb][2], c);
+        c = mfma_bf16(A2, b[cb][1], c);
+        c = mfma_bf16(A2, b[cb][0], c);
+        c = mfma_bf16(A1, b[cb][1], c);
+        c = mfma_bf16(A1, b[cb][0], c);
         acc[0][n] = c;
+        if (BB == 1 && n + 1 < NT) {
+#pragma unroll
+            for (int q = 0; q < 3; q++) b[0][q] = bp[(q * NT + n + 1) * 64];
+        }
     }
 }
 
@@ -766,7 +775,7 @@ struct MRound {
 // SPLIT: the products of a phase as three-way bf16 splits (compute_phase_split; SLJ == 2: a phase is one 32-plane block).  W then points to
 // the split weights [block][K][nIn / 32][3][NT][64][8 bf16] and a slice is 3 NT KiB instead of 128 COUT bytes per plane pair.
 template <int NT, int NW, int NJ, int SLJ, int MO, int NB = 2, bool LATE = false, bool PERSIST = false, bool SPLIT = false>
-__global__ __launch_bounds__(64 * NW, 4) void conv_mround_mfma_kernel(
+__global__ __launch_bounds__(64 * NW, NW == 12 ? 3 : 4) void conv_mround_mfma_kernel(
     const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ Y,
     const int32_t *__restrict__ tile_sub_start, const int32_t *__restrict__ tile_seg,
     const int32_t *__restrict__ sub_src, const uint8_t *__restrict__ sub_dst, int64_t n_dst, int K, int CIN, int n_tiles,
@@ -1052,7 +1061,7 @@ __global__ __launch_bounds__(64 * NW, 4) void conv_mround_mfma_kernel(
                     if (valid)
                     {
                         const float *wsl = wbuf + (size_t)(s * MO + gi) * WSLICE;
-                        if constexpr (SPLIT) compute_phase_split<NT>(wsl, a_c[s], acc, lane);
+                        if constexpr (SPLIT) compute_phase_split<NT, (NJ >= 12 ? 1 : 2)>(wsl, a_c[s], acc, lane);
                         else compute_phase<NT, SLJ, 1, 1, COUT>(wsl, a_c[s], acc, g, r16);
                     }
                     MST(3);
@@ -1119,7 +1128,7 @@ __global__ __launch_bounds__(64 * NW, 4) void conv_mround_mfma_kernel(
                     if (valid)
                     {
                         const float *wsl = wbuf + (size_t)((NB == 3 ? bcur : (phase & 1)) * MO + gi) * WSLICE;
-                        if constexpr (SPLIT) compute_phase_split<NT>(wsl, a_c[s], acc, lane);
+                        if constexpr (SPLIT) compute_phase_split<NT, (NJ >= 12 ? 1 : 2)>(wsl, a_c[s], acc, lane);
                         else compute_phase<NT, SLJ, 1, 1, COUT>(wsl, a_c[s], acc, g, r16);
                     }
                     if (late) requests();
@@ -1517,9 +1526,15 @@ static ConvPlan plan_tile(int nIn, int nOut, int K, int64_t n_dst) {
                 const bool split = product_mode() == 1 && K + 1 <= 64 && nIn % 32 == 0 && nIn >= 64 && nIn <= 192 &&
                                    (nOut == 64 || nOut == 96 || nOut == 128 || nOut == 160 || nOut == 192);
                 if (split) {
-                    p.blocks = nOut == 64 ? 1 : (nOut == 192 ? 3 : 2);
+                    p.blocks = nOut == 64 || nOut == 96 ? 1 : (nOut == 192 ? 3 : 2);
                     p.nw = 16; p.mo = 2; p.g = 3; p.nb = 2; p.split = true; p.persist = false;
                     p.slj = 6;   // sizes the LDS: 2 buffers x 2 offsets x 3 nt KiB of split slices
+                    // 96 columns in ONE block: 72 KB of split slices leave 72 KB for the tile -- 192 rows, twelve waves (two blocks of 48
+                    // columns on 256-row tiles: 116 against NEW fp32-equivalent TFLOP/s at level 2; SEI_SPLIT_L2_BLOCKS=2 in experiment builds)
+                    if (nOut == 96) p.nw = 12;
+#ifdef SEI_EXPERIMENTS
+                    if (nOut == 96 && getenv("SEI_SPLIT_L2_BLOCKS") && atoi(getenv("SEI_SPLIT_L2_BLOCKS")) == 2) { p.blocks = 2; p.nw = 16; }
+#endif
                 }
                 const int cols = nOut / p.blocks;
                 const Round16 r16p = (!split && K + 1 <= 64) ? round16_plan(cols / 16, nIn) : Round16{0, 0, 0, 2};
@@ -1598,19 +1613,22 @@ static int launch_round(const TiledRules &t, const ConvPlan &p, const float *X, 
                         int nIn, const float *init, double *stats, hipStream_t st, const ConvEpilogue &ep) {
     // one register set of A fragments refilled a phase after use (NJ = nIn / 16 > 0) where 128 registers hold it; the narrower
     // column blocks keep the per-phase gathers and three workgroups per CU
-    if (p.nw == 16 && p.g == 3 && p.split) {   // [r5] opt-in: products as three-way bf16 splits (W = conv_split_weights' layout)
-#define MROUND16S(NJ_)                                                                                                     \
-        if (nIn == 16 * NJ_) {                                                                                             \
-            SEI_TRY(ensure_max_lds((const void *)conv_mround_mfma_kernel<NT, 16, NJ_, 2, 2, 2, false, false, true>, 160 * 1024)); \
-            conv_mround_mfma_kernel<NT, 16, NJ_, 2, 2, 2, false, false, true><<<((t.n_tiles * p.blocks + 7) / 8) * 8, 1024, p.lds_bytes, st>>>( \
+    if ((p.nw == 16 || p.nw == 12) && p.g == 3 && p.split) {   // [r5] opt-in: products as three-way bf16 splits (W = conv_split_weights' layout)
+#define MROUND16S(NW_, NJ_)                                                                                                \
+        if (p.nw == NW_ && nIn == 16 * NJ_) {                                                                              \
+            SEI_TRY(ensure_max_lds((const void *)conv_mround_mfma_kernel<NT, NW_, NJ_, 2, 2, 2, false, false, true>, 160 * 1024)); \
+            conv_mround_mfma_kernel<NT, NW_, NJ_, 2, 2, 2, false, false, true><<<((t.n_tiles * p.blocks + 7) / 8) * 8, 64 * NW_, p.lds_bytes, st>>>( \
                 X, W, bias, Y, t.tile_sub_start, t.tile_seg, t.sub_src, t.sub_dst, t.n_dst, t.K, nIn, t.n_tiles, init,     \
                 NT * 16 * p.blocks, p.blocks, stats, ep, nullptr);                                                         \
             SEI_LAUNCH_CHECK();                                                                                            \
             return 0;                                                                                                      \
         }
-        if constexpr (NT == 3) { MROUND16S(4) MROUND16S(6) MROUND16S(8) }
-        if constexpr (NT == 4) { MROUND16S(4) MROUND16S(6) MROUND16S(8) MROUND16S(10) MROUND16S(12) }
-        if constexpr (NT == 5) { MROUND16S(8) MROUND16S(10) MROUND16S(12) }
+        if constexpr (NT == 6) { MROUND16S(12, 4) MROUND16S(12, 6) MROUND16S(12, 8) }
+        if constexpr (NT == 4) { MROUND16S(16, 4) MROUND16S(16, 6) MROUND16S(16, 8) MROUND16S(16, 10) MROUND16S(16, 12) }
+        if constexpr (NT == 5) { MROUND16S(16, 8) MROUND16S(16, 10) MROUND16S(16, 12) }
+#ifdef SEI_EXPERIMENTS   // SEI_SPLIT_L2_BLOCKS=2
+        if constexpr (NT == 3) { MROUND16S(16, 4) MROUND16S(16, 6) MROUND16S(16, 8) }
+#endif
 #undef MROUND16S
         SEI_FAIL("conv_forward: no split-product instantiation for this plan");
     }

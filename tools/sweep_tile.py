@@ -45,7 +45,7 @@ def main():
             scn.set_product_mode("bf16x3" if "+split" in plan else "fp32")
             os.environ["SEI_CONV_KERNEL"] = {"cols": "cols", "wave": "wave"}.get(plan, "rounds" if "rounds" in plan else "tile")
             os.environ["SEI_TILE_ROUNDS"] = "1" if "rounds" in plan else "0"   # conv_round_mfma_kernel (two-offset rounds)
-            for kv in ("SEI_ROUND_JIT", "SEI_ROUND_RING", "SEI_ROUND_SLJ", "SEI_ROUND_NOFF", "SEI_ROUND_NW", "SEI_ROUND_MO", "SEI_ROUND_LONG", "SEI_ROUND_NB", "SEI_ROUND_FAM", "SEI_ROUND_LATE", "SEI_ROUND_PERSIST"):
+            for kv in ("SEI_ROUND_JIT", "SEI_ROUND_RING", "SEI_ROUND_SLJ", "SEI_ROUND_NOFF", "SEI_ROUND_NW", "SEI_ROUND_MO", "SEI_ROUND_LONG", "SEI_ROUND_NB", "SEI_ROUND_FAM", "SEI_ROUND_LATE", "SEI_ROUND_PERSIST", "SEI_SPLIT_L2_BLOCKS"):
                 os.environ.pop(kv, None)
             if plan in ("rounds+jit", "rounds-jit"):      # force / forbid the refilled-fragment form
                 os.environ["SEI_ROUND_JIT"] = "1" if plan == "rounds+jit" else "0"
