@@ -4,7 +4,7 @@
 #   gpurun -- "SEI_COMMIT=$(git rev-parse --short HEAD) bash tools/traffic.sh"   (the box has no .git)
 export SEI_GEN_WORKERS=1 TMPDIR=/tmp
 out=gpurun_out/traffic; rm -rf $out; mkdir -p $out
-cmd="python3 bench.py --steps 1 --warmup 1 --cpu-events 0 --no-prof --batches 1"
+cmd="python3 bench.py --steps 1 --warmup 1 --cpu-events 0 --no-prof --batches 1 --no-optin-leg"
 timeout -k 10 500 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/f -- $cmd > $out/f.log 2>&1
 timeout -k 10 500 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/w -- $cmd > $out/w.log 2>&1
 python3 - <<'PY'
@@ -29,7 +29,7 @@ def per_launch(keys):
 n, f, w = per_launch(conv)
 nd, fd, wd = per_launch(dw)
 res = {"commit": os.environ.get("SEI_COMMIT"),
-       "source": "tools/traffic.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 1 --warmup 1 --cpu-events 0 --no-prof --batches 1",
+       "source": "tools/traffic.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 1 --warmup 1 --cpu-events 0 --no-prof --batches 1 --no-optin-leg",
        "workload": "dune3d train 64 events x 50000 voxels 900^3 tracks",
        "kernel": "conv_round_mfma_kernel + conv_mround_mfma_kernel + conv_tile_mfma_kernel + conv_wave_mfma_kernel (all forward + dX launches)",
        "launches": n, "fetch_size_bytes_per_launch": f, "write_size_bytes_per_launch": w,
