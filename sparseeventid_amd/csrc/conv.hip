@@ -93,13 +93,14 @@ __global__ void weights_split_kernel(const float *__restrict__ Wnat, uint32_t *_
     const int blk = (int)(r / K);
     const int row = 32 * sl + 8 * (lane >> 4) + 2 * jp, col = 16 * (blk * nt + n) + (lane & 15);
     const float x = Wnat[((size_t)k * rows + row) * cols + col], y = Wnat[((size_t)k * rows + row + 1) * cols + col];
-    const unsigned ux = __float_as_uint(x), uy = __float_as_uint(y);
-    const unsigned x1 = ux & 0xFFFF0000u, y1 = uy & 0xFFFF0000u;
+    // round-to-nearest-even bf16 of what is left, three times (the same arithmetic as split_pair in conv_fwd.hip)
+    auto rne = [](float v) { const unsigned u = __float_as_uint(v); return (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u; };
+    const unsigned x1 = rne(x), y1 = rne(y);
     const float rx = x - __uint_as_float(x1), ry = y - __uint_as_float(y1);
-    const unsigned x2 = __float_as_uint(rx) & 0xFFFF0000u, y2 = __float_as_uint(ry) & 0xFFFF0000u;
+    const unsigned x2 = rne(rx), y2 = rne(ry);
     const float rx2 = rx - __uint_as_float(x2), ry2 = ry - __uint_as_float(y2);
-    const unsigned part[3] = {(y1 & 0xFFFF0000u) | (x1 >> 16), (y2 & 0xFFFF0000u) | (x2 >> 16),
-                              (__float_as_uint(ry2) & 0xFFFF0000u) | (__float_as_uint(rx2) >> 16)};
+    const unsigned x3 = rne(rx2), y3 = rne(ry2);
+    const unsigned part[3] = {y1 | (x1 >> 16), y2 | (x2 >> 16), y3 | (x3 >> 16)};
     // [block][k][s][part][n][lane][4 words]
     const size_t slice = ((size_t)(blk * K + k) * NS + sl) * (size_t)(3 * nt * 256);
 #pragma unroll

@@ -688,8 +688,8 @@ __device__ unsigned long long g_mstamps[16][16];
 #endif
 
 // ---- fp32 products from THREE-WAY bf16 splits on the bf16 matrix pipe (opt-in: sei_set_product_mode(1)) [r5]
-// x = x1 + x2 + x3 EXACTLY, each part the next 8 mantissa bits of x (truncation: the parts are bf16 numbers and the residuals are
-// exact fp32 subtractions; bf16 has fp32's exponent range, so no scaling).  a b = sum of nine exact bf16 x bf16 products, of which
+// x = x1 + x2 + x3 EXACTLY, each part the bf16 nearest to what is left (the residuals are exact fp32 subtractions, the third one
+// is itself a bf16 number; bf16 has fp32's exponent range, so no scaling; |x2| <= 2^-8 |x|, |x3| <= 2^-16 |x|).  a b = sum of nine exact bf16 x bf16 products, of which
 // the six largest are accumulated in fp32 by v_mfma_f32_16x16x32_bf16 (the three dropped ones are below 2^-23 |a b|: the size of
 // the rounding error of one fp32 product).  16 cycles per 16 x 16 x 32 block and part pair: 96 cycles per 32 input planes and
 // column tile against 256 on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32: 8 x 32).
@@ -698,16 +698,20 @@ typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 mfma_bf16(u32x4_t a, u32x4_t b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
-// (x, y) -> three words of two packed bf16 each (x in the low half): parts 1, 2, 3
+// (x, y) -> three words of two packed bf16 each (x in the low half): parts 1, 2, 3.  Each part is the round-to-nearest-even
+// bf16 of what is left (v_cvt_pk_bf16_f32); the residuals are exact fp32 subtractions and the third residual IS a bf16 number.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk_bf16(float x, float y) {
+    const f32x2_t v = {x, y};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
 __device__ __forceinline__ void split_pair(float x, float y, unsigned &p1, unsigned &p2, unsigned &p3) {
-    const unsigned ux = __float_as_uint(x), uy = __float_as_uint(y);
-    const unsigned x1 = ux & 0xFFFF0000u, y1 = uy & 0xFFFF0000u;
-    p1 = __builtin_amdgcn_perm(y1, x1, 0x07060302u);
-    const float rx = x - __uint_as_float(x1), ry = y - __uint_as_float(y1);
-    const unsigned x2 = __float_as_uint(rx) & 0xFFFF0000u, y2 = __float_as_uint(ry) & 0xFFFF0000u;
-    p2 = __builtin_amdgcn_perm(y2, x2, 0x07060302u);
-    const float rx2 = rx - __uint_as_float(x2), ry2 = ry - __uint_as_float(y2);
-    p3 = __builtin_amdgcn_perm(__float_as_uint(ry2), __float_as_uint(rx2), 0x07060302u);
+    p1 = cvt_pk_bf16(x, y);
+    const float rx = x - __uint_as_float(p1 << 16), ry = y - __uint_as_float(p1 & 0xFFFF0000u);
+    p2 = cvt_pk_bf16(rx, ry);
+    const float rx2 = rx - __uint_as_float(p2 << 16), ry2 = ry - __uint_as_float(p2 & 0xFFFF0000u);
+    p3 = cvt_pk_bf16(rx2, ry2);
 }
 // One 32-plane phase for one sub-chunk.  a[0], a[1]: the lane's 8 consecutive planes 8 g .. 8 g + 7 of the slice for rule row r16
 // (the A layout of the 16 x 16 x 32 block).  wb: this offset's slice in LDS, [part][column tile][lane][8 bf16] (weights_split_kernel):
