@@ -15,6 +15,7 @@
 //   no atomics; every dst row is written to HBM exactly once.  Tiles are sized so that 2-6 workgroups share
 //   a CU: the barrier / gather latency of one workgroup is covered by its neighbours' MFMAs.
 #include "common.h"
+#include <type_traits>
 #include "conv_tile.h"
 
 #include <stdlib.h>
@@ -127,9 +128,14 @@ __device__ __forceinline__ void load_b(const float *__restrict__ wrow, int r16, 
 
 // one (k, slice) phase for a wave owning MS sub-chunks: straight-line, so the LDS reads of step
 // e+1 are scheduled under the MFMAs of step e.
-template <int NT, int SLJ, int MS, int MAXS, int COUT>
+struct NoSide { __device__ __forceinline__ void operator()(int, int) const {} };
+// side(st, tok): work of the wave that does not depend on this phase's products, issued BEHIND the MFMAs of step st, so that it
+// runs while those (and the other waves' MFMAs) occupy the matrix pipe instead of in front of / behind the whole block.  `tok`
+// is an opaque zero that "comes from" the step's last MFMA: side work must hang its conditions on it, or hipcc hoists a
+// conditional block of side work -- loads and all -- in front of the MFMA block ([r5] conv_mround_mfma_kernel, two long phases).
+template <int NT, int SLJ, int MS, int MAXS, int COUT, class Side = NoSide>
 __device__ __forceinline__ void compute_phase(const float *__restrict__ wb, const float4 (&a)[MAXS][SLJ],
-                                              f32x4 (&acc)[MAXS][NT], int g, int r16) {
+                                              f32x4 (&acc)[MAXS][NT], int g, int r16, Side side = Side()) {
     // B operands are read from LDS one step ahead of the MFMAs that consume them
     constexpr int STEPS = 4 * SLJ;
     float b[2][NT];
@@ -159,6 +165,11 @@ __device__ __forceinline__ void compute_phase(const float *__restrict__ wb, cons
                 acc[m][n] = mfma16(av, b[st & 1][n], acc[m][n]);
 #endif
             }
+        }
+        if constexpr (!std::is_same<Side, NoSide>::value) {
+            int tok = 0;
+            asm volatile("" : "+s"(tok) : "v"(acc[MS - 1][NT - 1]));
+            side(st, tok);
         }
     }
 }
@@ -786,6 +797,11 @@ __global__ __launch_bounds__(64 * NW, NW == 12 ? 3 : 4) void conv_mround_mfma_ke
     const float *__restrict__ init, int ldy, int blocks, double *__restrict__ stats, ConvEpilogue ep, int *__restrict__ work) {
     extern __shared__ float lds[];
     constexpr int NP = NJ / SLJ;   // phases of a round
+#ifdef SEI_NO_SIDE_WORK   // experiment builds: the schedule before the side work
+    constexpr bool SIDE = false;
+#else
+    constexpr bool SIDE = NP == 2 && MO == 2 && !SPLIT && !PERSIST;   // write-back + planning inside the MFMA block
+#endif
     static_assert(NJ % SLJ == 0 && NP >= 2, "NP >= 3: the refilled-fragment schedule; NP == 2: two long phases per round");
     static_assert(MO >= 2 && MO <= 4 && MO <= NP, "group g of a round is written back in phase g - 1 of the next one");
     static_assert(NB == 2 || (NB == 3 && NP >= 3), "the third weight buffer belongs to the refilled-fragment schedule");
@@ -1047,6 +1063,33 @@ __global__ __launch_bounds__(64 * NW, NW == 12 ? 3 : 4) void conv_mround_mfma_ke
                     for (int jj = 0; jj < SLJ; jj++)
                         a_c[1 - s][0][jj] = load_a(X, s == 0 ? rowc : rown, CIN, SPLIT ? 32 * (1 - s) + 8 * g + 4 * jj : 16 * (SLJ * (1 - s) + jj) + 4 * g);
                     asm volatile("" ::: "memory");
+                    if constexpr (SIDE) {
+                        // [r5] EVERY group of the previous round is added behind a barrier of this one -- group q in phase q, from
+                        // `pacc` -- and that write-back, the planning of round r + 3 and its index loads are issued INSIDE the
+                        // MFMA block (compute_phase: side work), not in front of it: +2.9 % at level 1
+                        // (profiles/r05_side_work_ab.log; the same in the short phases of the NP >= 3 schedule: -2 ... -7 %)
+                        if (s == 0) {
+                            if (pend_g != 0) {
+#pragma unroll
+                                for (int nn = 0; nn < NT; nn++) pacc[nn] = acc[0][nn];
+                            }
+#pragma unroll
+                            for (int nn = 0; nn < NT; nn++) acc[0][nn] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        }
+                        auto side = [&](int st, int tok) {
+                            if (s == 0 && st == 0) {
+                                r3 = plan(cx, r2.q0 + cnt_of(r2) + tok, last_of(r2));
+                                i3 = load_idx(cx, r3);
+                                asm volatile("" ::: "memory");
+                            }
+                            if (st == 1 && pend_g + tok == s + 1) {
+                                rmw(pacc, pend_d4, pend_nv);
+                                pend_g = 0;
+                            }
+                        };
+                        if (valid) compute_phase<NT, SLJ, 1, 1, COUT>(wbuf + (size_t)(s * MO + gi) * WSLICE, a_c[s], acc, g, r16, side);
+                        else { side(0, 0); side(1, 0); }
+                    } else {
                     if (s == 0) {
                         r3 = plan(cx, r2.q0 + cnt_of(r2), last_of(r2));
                         i3 = load_idx(cx, r3);
@@ -1067,6 +1110,7 @@ __global__ __launch_bounds__(64 * NW, NW == 12 ? 3 : 4) void conv_mround_mfma_ke
                         const float *wsl = wbuf + (size_t)(s * MO + gi) * WSLICE;
                         if constexpr (SPLIT) compute_phase_split<NT, (NJ >= 12 ? 1 : 2)>(wsl, a_c[s], acc, lane);
                         else compute_phase<NT, SLJ, 1, 1, COUT>(wsl, a_c[s], acc, g, r16);
+                    }
                     }
                     MST(3);
                     MST_ADD(8, valid ? 1 : 0);
@@ -1144,8 +1188,13 @@ __global__ __launch_bounds__(64 * NW, NW == 12 ? 3 : 4) void conv_mround_mfma_ke
                 });
             }
             const int nv = __popcll(__ballot(rowc >= 0) & 0xFFFFull);
-            if (valid && gi == 0) rmw(acc[0], ic.d4, nv);
-            if (valid && gi > 0) {
+            if (SIDE && valid) {   // group gi waits for phase gi of the next round
+                pend_g = gi + 1;
+                pend_d4 = ic.d4;
+                pend_nv = nv;
+            }
+            if (!SIDE && valid && gi == 0) rmw(acc[0], ic.d4, nv);
+            if (!SIDE && valid && gi > 0) {
                 if (MO > 2) {   // MO == 2: the sums stay in acc, which is cleared only after they have been added (phase 0)
 #pragma unroll
                     for (int nn = 0; nn < NT; nn++) pacc[nn] = acc[0][nn];
@@ -1159,11 +1208,11 @@ __global__ __launch_bounds__(64 * NW, NW == 12 ? 3 : 4) void conv_mround_mfma_ke
             MST_ADD(10, 1);
         }
         MST(4);
-        // the last round's groups 1 .. MO-1, in order
+        // the last round's groups 1 .. MO-1, in order (SIDE: groups 0 .. MO-1, pend_g = group + 1; the sums are still in acc)
 #pragma unroll
-        for (int gq = 1; gq < MO; gq++) {
+        for (int gq = 1; gq < MO + (SIDE ? 1 : 0); gq++) {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" SEI_BARRIER_INSN ::: "memory");
-            if (pend_g == gq) rmw(MO == 2 ? acc[0] : pacc, pend_d4, pend_nv);
+            if (pend_g == gq) rmw(MO == 2 || SIDE ? acc[0] : pacc, pend_d4, pend_nv);
         }
     }
     __syncthreads();
