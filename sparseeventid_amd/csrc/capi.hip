@@ -765,7 +765,7 @@ static int conv_forward_impl(sei_rulebook_t *rb, const float *X, const float *W,
         bias = ab.p;
     }
     const int kind = nIn == 32 && nOut == 32 ? PROF_CONV_FWD_C32 : PROF_CONV_FWD;
-    if (p.kind != 1 && p.kind != 4) {  // natural weight layout: no copy
+    if (p.kind != 1 && p.kind != 4 && !(p.kind == 2 && p.col_group == -2)) {  // natural weight layout: no copy
         if (p.kind >= 2) {
             SEI_TRY(aw.stage(W, (size_t)t->K * nIn * nOut, st));
             W = aw.p;
@@ -874,7 +874,7 @@ static int conv_backward_input_impl(sei_rulebook_t *rb, const float *dY, const f
         rc = conv_transform_weights(W, Wt, t->K, nIn, nOut, true, rb->submanifold, 0, 1, st);
         if (!rc) rc = conv_split_weights(Wt, Wt + (size_t)t->K * nIn * nOut, t->K, nOut, nIn, p.nt, st);
     } else {
-        rc = conv_transform_weights(W, Wt, t->K, nIn, nOut, true, rb->submanifold, (p.kind == 1 || p.kind == 4) ? p.col_group : 0,
+        rc = conv_transform_weights(W, Wt, t->K, nIn, nOut, true, rb->submanifold, (p.kind == 1 || p.kind == 4 || (p.kind == 2 && p.col_group == -2)) ? p.col_group : 0,
                                     p.kind == 1 ? p.blocks : 1, st);
     }
     if (!rc && p.split) {

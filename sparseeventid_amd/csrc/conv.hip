@@ -43,6 +43,12 @@ __device__ inline int permute_col(int c, int width) {
 // columns of every group permuted, or (blocks > 1) [block][K][rows][cols / blocks] so that each column block is
 // a contiguous panel for the workgroups that own it
 __device__ inline size_t weight_index(int ks, int row, int col, int K, int rows, int cols, int col_group, int blocks) {
+    if (col_group == -2) {   // [r5] wave kernel at 32 x 32 planes: [k][16-plane slice j][half h][lane = 16 g + r][(e & 1) * 2 + n]:
+        // lane (g, r) finds planes 16j+4g+e (e = 2h, 2h+1) of its two columns 2r + n (the wave kernel's natural-layout column
+        // assignment: wload_b<2> reads columns 2r, 2r+1) in ONE 16-byte word, a slice in two
+        const int j = row >> 4, g = (row >> 2) & 3, e = row & 3, n = col & 1, r = col >> 1;
+        return ((((size_t)ks * (rows >> 4) + j) * 2 + (e >> 1)) * 64 + (16 * g + r)) * 4 + (e & 1) * 2 + n;
+    }
     if (col_group < 0) {  // column-owner kernel: [k][column tile][16-row group][lane = (row % 16) / 4 * 16 + col % 16][row % 4]
         const int cb = col >> 4, j = row >> 4, ln = ((row & 15) >> 2) * 16 + (col & 15);
         return ((((size_t)ks * (cols >> 4) + cb) * (rows >> 4) + j) * 64 + ln) * 4 + (row & 3);

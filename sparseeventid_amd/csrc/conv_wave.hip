@@ -121,6 +121,16 @@ __device__ __forceinline__ void wprefetch(const float *__restrict__ X, const flo
     for (int e = 0; e < 4; e++) wload_b<NT>(wn + (size_t)e * ldy, r16, b[e]);
 }
 
+// [r5] B operands of slice j of offset k from the PACKED copy of the 32 x 32 weights (conv.hip: weight_index, col_group -2): two
+// global_load_dwordx4 per slice instead of four dwordx2 -- every vector-memory instruction costs the CU's address path the same
+// ~1 KiB whatever it carries, and at 32 planes (one sub-chunk per offset and tile) the B loads are two thirds of them
+__device__ __forceinline__ void wload_b_packed(const float *__restrict__ Wp, int NS, int k, int j, int lane, float (&b)[4][2]) {
+    const float4 *p = reinterpret_cast<const float4 *>(Wp) + ((size_t)(k * NS + j) * 2) * 64 + lane;
+    const float4 v0 = p[0], v1 = p[64];
+    b[0][0] = v0.x; b[0][1] = v0.y; b[1][0] = v0.z; b[1][1] = v0.w;
+    b[2][0] = v1.x; b[2][1] = v1.y; b[3][0] = v1.z; b[3][1] = v1.w;
+}
+
 // One group = MS sub-chunks of offset kc: all NS slices, then the read-modify-write of the tile rows.  On entry
 // (a0, b0) hold slice 0 of this group; on exit they hold slice 0 of the NEXT group (rows rn, offset kn).  The slices
 // ping-pong between two operand sets so that no register copies sit between the MFMAs, and every slice's loads are
@@ -193,12 +203,12 @@ __device__ __forceinline__ void wgroup(const float *__restrict__ X, const float 
 // group's first MFMA: a whole group (32 MFMAs + the tile read-modify-write) of cover, two operand sets (cur / nxt) that the
 // caller swaps between groups (no register copies).  Every request is unconditional (a missing sub-chunk re-reads row 0): the
 // number of requests in flight is then a compile-time constant and hipcc's own vmcnt waits stay exact.
-template <int NT, int G, int MS>
+template <int NT, int G, int MS, bool PACKED = false>
 __device__ __forceinline__ void wgroup2(const float *__restrict__ X, const float *__restrict__ wl, int ldy, int CIN, int kn,
                                         const int (&rc)[G], const int (&rn)[G], const uint32_t (&d4)[G], const int (&src)[G],
                                         float *acc_tile, int g, int r16, const float4 (&ac0)[G], const float (&bc0)[4][NT],
                                         const float4 (&ac1)[G], const float (&bc1)[4][NT], float4 (&an0)[G], float (&bn0)[4][NT],
-                                        float4 (&an1)[G], float (&bn1)[4][NT], WStamp &st) {
+                                        float4 (&an1)[G], float (&bn1)[4][NT], WStamp &st, const float *wpacked = nullptr) {   // PACKED: wpacked = the packed weights
     constexpr int NC = 16 * NT;
     f32x4 acc[MS][NT];
 #pragma unroll
@@ -209,9 +219,13 @@ __device__ __forceinline__ void wgroup2(const float *__restrict__ X, const float
     for (int j = 0; j < 2; j++) {
 #pragma unroll
         for (int m = 0; m < G; m++) (j == 0 ? an0 : an1)[m] = wload_a<SEI_WAVE_ABL>(X, rn[m], CIN, 16 * j + 4 * g);
-        const float *wn = wl + ((size_t)kn * CIN + 16 * j) * ldy;
+        if constexpr (PACKED && NT == 2) {   // (a compile-time choice: a branch around the loads would cost hipcc's exact waits)
+            wload_b_packed(wpacked, 2, kn, j, 16 * g + r16, j == 0 ? bn0 : bn1);
+        } else {
+            const float *wn = wl + ((size_t)kn * CIN + 16 * j) * ldy;
 #pragma unroll
-        for (int e = 0; e < 4; e++) wload_b<NT>(wn + (size_t)e * ldy, r16, (j == 0 ? bn0 : bn1)[e]);
+            for (int e = 0; e < 4; e++) wload_b<NT>(wn + (size_t)e * ldy, r16, (j == 0 ? bn0 : bn1)[e]);
+        }
     }
     __builtin_amdgcn_sched_barrier(0);   // the requests are ISSUED before this group's MFMAs
     WSTAMP(1);
@@ -244,7 +258,7 @@ constexpr int wave_occ(int nt, int g) {
     return est <= 120 ? 4 : (est <= 160 ? 3 : (est <= 248 ? 2 : 1));
 }
 
-template <int NT, int G>
+template <int NT, int G, bool PACKED = false>
 __global__ __launch_bounds__(64, wave_occ(NT, G)) void conv_wave_mfma_kernel(
     const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ Y,
     const int32_t *__restrict__ tile_sub_start, const int32_t *__restrict__ tile_seg,
@@ -349,6 +363,10 @@ __global__ __launch_bounds__(64, wave_occ(NT, G)) void conv_wave_mfma_kernel(
                 for (int e = 0; e < 4; e++) wload_b<NT>(wn + (size_t)e * ldy, r16, pb1[e]);
 #pragma unroll
                 for (int m = 0; m < G; m++) a0[m] = wload_a<SEI_WAVE_ABL>(X, r0[m], CIN, 4 * g);   // every sub-chunk slot (wprefetch skipped the missing ones)
+                if constexpr (PACKED && NT == 2) {   // (the loads above read the packed copy as if it were natural: overwritten here)
+                    wload_b_packed(W, 2, it0.k, 0, lane, b0);
+                    wload_b_packed(W, 2, it0.k, 1, lane, pb1);
+                }
             }
             bool flip = false;
             while (it0.k < K) {
@@ -361,10 +379,10 @@ __global__ __launch_bounds__(64, wave_occ(NT, G)) void conv_wave_mfma_kernel(
                 }
 #define WGROUP2(MS_)                                                                                                         \
                 do {                                                                                                         \
-                    if (!flip) wgroup2<NT, G, (MS_ <= G ? MS_ : 1)>(X, wl, ldy, CIN, kn, rc, rn, ix0.d4, ix0.src, acc_tile, g, r16, \
-                                                                     a0, b0, pa1, pb1, qa0, qb0, qa1, qb1, st);              \
-                    else wgroup2<NT, G, (MS_ <= G ? MS_ : 1)>(X, wl, ldy, CIN, kn, rc, rn, ix0.d4, ix0.src, acc_tile, g, r16,  \
-                                                               qa0, qb0, qa1, qb1, a0, b0, pa1, pb1, st);                    \
+                    if (!flip) wgroup2<NT, G, (MS_ <= G ? MS_ : 1), PACKED>(X, wl, ldy, CIN, kn, rc, rn, ix0.d4, ix0.src, acc_tile, g, r16, \
+                                                                     a0, b0, pa1, pb1, qa0, qb0, qa1, qb1, st, W); \
+                    else wgroup2<NT, G, (MS_ <= G ? MS_ : 1), PACKED>(X, wl, ldy, CIN, kn, rc, rn, ix0.d4, ix0.src, acc_tile, g, r16,  \
+                                                               qa0, qb0, qa1, qb1, a0, b0, pa1, pb1, st, W); \
                 } while (0)
                 if (G == 1 || ix0.cnt == 1) WGROUP2(1);
                 else if (G == 2 || ix0.cnt == 2) WGROUP2(2);
@@ -499,6 +517,9 @@ bool plan_wave(int nIn, int nOut, int K, int64_t n_dst, ConvPlan *p) {
     if (!forced && !env && conv_rounds_64(nIn, nOut, K, n_dst)) return false;   // [r5] sixteen-wave multi-offset rounds (conv_fwd.hip)
     if ((size_t)tr * nt * 16 * sizeof(float) > 64 * 1024) return false;
     p->kind = 2; p->tile_rows = tr; p->col_group = 0; p->blocks = tiles / nt; p->nt = nt; p->g = g;
+#ifndef SEI_WAVE_NO_PACKED_W
+    if (GROUP_AHEAD && nt == 2 && g == 2 && nIn == 32 && nOut == 32) p->col_group = -2;   // [r5] packed B operands (wload_b_packed)
+#endif
     p->lds_bytes = (size_t)tr * nt * 16 * sizeof(float);
     return true;
 }
@@ -507,6 +528,16 @@ template <int NT, int G>
 static int launch_wave(const TiledRules &t, const ConvPlan &p, const float *X, const float *W, const float *bias, float *Y,
                        int nIn, int nOut, const float *init, double *stats, hipStream_t st, const ConvEpilogue &ep) {
     const int nwork = t.n_tiles * p.blocks;
+    if constexpr (NT == 2 && G == 2) {
+        if (p.col_group == -2) {   // [r5] 32 x 32 planes: B operands from the packed copy (plan_wave)
+            conv_wave_mfma_kernel<NT, G, true><<<((nwork + 7) / 8) * 8, 64, p.lds_bytes, st>>>(
+                X, W, bias, Y, t.tile_sub_start, t.tile_seg, t.sub_src, t.sub_dst, t.n_dst, t.K, nIn, t.n_tiles, init, nOut,
+                p.blocks, t.tile_rows, stats, ep);
+            SEI_LAUNCH_CHECK();
+            return 0;
+        }
+    }
+    if (p.col_group == -2) SEI_FAIL("conv_forward_wave: packed weights without the packed kernel");
     conv_wave_mfma_kernel<NT, G><<<((nwork + 7) / 8) * 8, 64, p.lds_bytes, st>>>(
         X, W, bias, Y, t.tile_sub_start, t.tile_seg, t.sub_src, t.sub_dst, t.n_dst, t.K, nIn, t.n_tiles, init, nOut,
         p.blocks, t.tile_rows, stats, ep);
