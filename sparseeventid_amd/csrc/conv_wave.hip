@@ -484,7 +484,7 @@ static bool env_wave_plan(int nOut, int *nt, int *tr, int *g) {
     return false;
 }
 
-static bool wave_instantiated(int nt, int g) { return nt >= 1 && nt <= 8 && (g == 2 || (g == 4 && nt <= 6) || (g == 3 && nt <= 8)); }
+static bool wave_instantiated(int nt, int g) { return nt >= 1 && nt <= 8 && (g == 2 || (g == 1 && nt == 2) || (g == 4 && nt <= 6) || (g == 3 && nt <= 8)); }
 #endif
 
 // Default use: the 32- and 64-column layers (levels 0-1 of the DUNE network).  There the workgroup-tile kernel's
@@ -504,7 +504,15 @@ bool plan_wave(int nIn, int nOut, int K, int64_t n_dst, ConvPlan *p) {
         if (tiles % c == 0) { nt = c; break; }
     if (nt == 1 && tiles > 1) return false;  // 11 / 13 column tiles: the workgroup-tile kernel
     int tr = 64, g = 2;
+#ifdef SEI_WAVE32_PLAN_R4   // experiment builds: round 2-4's plan for 32 columns
     if (nOut == 32) { tr = 128; g = 2; }
+#else
+    // [r5] 32 columns: 64-row tiles, one sub-chunk per group.  Almost every (tile, offset) of level 0 holds ONE sub-chunk; a group of
+    // two then spends a third of its vector-memory instructions on the missing one (every request of the group-ahead form is
+    // unconditional), and 8 KB tiles at 120 registers put 16 waves on a CU instead of 10-12: 0.703 vs 0.754 ms
+    // (profiles/r05_wave_packed_weights_ab.log)
+    if (nOut == 32) { tr = 64; g = 1; }
+#endif
     if (nOut == 64) { tr = 64; g = 3; }
     bool env = false;
 #ifdef SEI_EXPERIMENTS
@@ -518,7 +526,7 @@ bool plan_wave(int nIn, int nOut, int K, int64_t n_dst, ConvPlan *p) {
     if ((size_t)tr * nt * 16 * sizeof(float) > 64 * 1024) return false;
     p->kind = 2; p->tile_rows = tr; p->col_group = 0; p->blocks = tiles / nt; p->nt = nt; p->g = g;
 #ifndef SEI_WAVE_NO_PACKED_W
-    if (GROUP_AHEAD && nt == 2 && g == 2 && nIn == 32 && nOut == 32) p->col_group = -2;   // [r5] packed B operands (wload_b_packed)
+    if (GROUP_AHEAD && nt == 2 && g <= 2 && nIn == 32 && nOut == 32) p->col_group = -2;   // [r5] packed B operands (wload_b_packed)
 #endif
     p->lds_bytes = (size_t)tr * nt * 16 * sizeof(float);
     return true;
@@ -528,7 +536,7 @@ template <int NT, int G>
 static int launch_wave(const TiledRules &t, const ConvPlan &p, const float *X, const float *W, const float *bias, float *Y,
                        int nIn, int nOut, const float *init, double *stats, hipStream_t st, const ConvEpilogue &ep) {
     const int nwork = t.n_tiles * p.blocks;
-    if constexpr (NT == 2 && G == 2) {
+    if constexpr (NT == 2 && G <= 2) {
         if (p.col_group == -2) {   // [r5] 32 x 32 planes: B operands from the packed copy (plan_wave)
             conv_wave_mfma_kernel<NT, G, true><<<((nwork + 7) / 8) * 8, 64, p.lds_bytes, st>>>(
                 X, W, bias, Y, t.tile_sub_start, t.tile_seg, t.sub_src, t.sub_dst, t.n_dst, t.K, nIn, t.n_tiles, init, nOut,
@@ -552,7 +560,7 @@ int conv_forward_wave(const TiledRules &t, const ConvPlan &p, const float *X, co
                       int nIn, int nOut, const float *init, double *stats, hipStream_t st, const ConvEpilogue &ep) {
     // defaults (32 / 64 columns) and the forced-kernel plans (any column count, groups of 2)
     WAVE_CASE(1, 2) WAVE_CASE(2, 2) WAVE_CASE(3, 2) WAVE_CASE(4, 2) WAVE_CASE(5, 2) WAVE_CASE(6, 2) WAVE_CASE(7, 2) WAVE_CASE(8, 2)
-    WAVE_CASE(4, 3)
+    WAVE_CASE(4, 3) WAVE_CASE(2, 1)
 #ifdef SEI_EXPERIMENTS  // alternates reachable through SEI_WAVE_PLAN
     WAVE_CASE(1, 3) WAVE_CASE(2, 3) WAVE_CASE(3, 3) WAVE_CASE(5, 3) WAVE_CASE(6, 3) WAVE_CASE(7, 3) WAVE_CASE(8, 3)
     WAVE_CASE(1, 4) WAVE_CASE(2, 4) WAVE_CASE(3, 4) WAVE_CASE(4, 4) WAVE_CASE(5, 4) WAVE_CASE(6, 4)

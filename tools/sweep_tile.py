@@ -43,8 +43,12 @@ def main():
             # "default" = the tile kernel with one offset per phase (forced kind 1); every "rounds*" plan forces the round form
             # "rounds+split" (and "rounds+split:KNOB=..."): the opt-in product mode (three-way bf16 splits on the bf16 matrix pipe)
             scn.set_product_mode("bf16x3" if "+split" in plan else "fp32")
-            os.environ["SEI_CONV_KERNEL"] = {"cols": "cols", "wave": "wave"}.get(plan, "rounds" if "rounds" in plan else "tile")
+            os.environ["SEI_CONV_KERNEL"] = "wave" if plan.startswith("wave") else {"cols": "cols"}.get(plan, "rounds" if "rounds" in plan else "tile")
             os.environ["SEI_TILE_ROUNDS"] = "1" if "rounds" in plan else "0"   # conv_round_mfma_kernel (two-offset rounds)
+            os.environ.pop("SEI_WAVE_PLAN", None)
+            if plan.startswith("wave:"):                  # "wave:SEI_WAVE_PLAN=32:2,128,1" (nOut:nt,tile rows,group) -- note the commas: one knob only
+                k_, _, val = plan.split(":", 1)[1].partition("=")
+                os.environ[k_] = val
             for kv in ("SEI_ROUND_JIT", "SEI_ROUND_RING", "SEI_ROUND_SLJ", "SEI_ROUND_NOFF", "SEI_ROUND_NW", "SEI_ROUND_MO", "SEI_ROUND_LONG", "SEI_ROUND_NB", "SEI_ROUND_FAM", "SEI_ROUND_LATE", "SEI_ROUND_PERSIST", "SEI_SPLIT_L2_BLOCKS"):
                 os.environ.pop(kv, None)
             if plan in ("rounds+jit", "rounds-jit"):      # force / forbid the refilled-fragment form
@@ -53,7 +57,7 @@ def main():
                 for kv in plan.split(":", 1)[1].split(","):
                     k_, _, val = kv.partition("=")
                     os.environ[k_] = val
-            if plan in ("default", "cols", "wave", "forced-rounds") or plan.startswith("rounds"):
+            if plan in ("default", "cols", "forced-rounds") or plan.startswith("rounds") or plan.startswith("wave"):
                 os.environ.pop("SEI_FWD_PLAN", None)
             else:
                 os.environ["SEI_FWD_PLAN"] = plan
